@@ -1,0 +1,157 @@
+"""The oracle (CPU restatement) against the golden vectors produced by the real reference helpers."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+from oracle import geom_fma, projection_ref as pref, refinement_ref as rref, rle_ref
+
+Z = lambda name: np.load(os.path.join(gio.GOLDEN_DIR, name))
+
+
+def _geom_cases():
+    return [str(c) for c in Z("proj_helpers.npz")["cases"]]
+
+
+@pytest.mark.parametrize("case", _geom_cases())
+def test_geometry_numpy_restatement(case):
+    z = Z("proj_helpers.npz")
+    g = lambda k: z[f"{case}.{k}"]
+    cloud_h = pref.homogeneous_cloud(g("xyz"))
+    pts = pref.world_to_camera_inv(cloud_h, g("inv_pose"))
+    assert np.array_equal(pts, g("pts_cam"), equal_nan=True)
+    pix = pref.project_to_pixels(pts, g("K"))
+    assert np.array_equal(pix, g("pix"))
+    vis = pref.visibility(pts, pix, g("depth"))
+    assert np.array_equal(vis, g("vis"))
+    msk = pref.masked_points(pix, vis, g("masks").astype(np.float32))
+    assert np.array_equal(gio.pack_bool_rows(msk), g("masked"))
+
+
+@pytest.mark.parametrize("case", _geom_cases())
+def test_geometry_c_fma_chain(case):
+    """The explicit k-ascending fma chain reproduces the reference (NumPy/OpenBLAS) bit for bit."""
+    z = Z("proj_helpers.npz")
+    g = lambda k: z[f"{case}.{k}"]
+    pts, pix, vis = geom_fma.view(g("xyz"), g("inv_pose"), g("K"), g("depth"))
+    assert np.array_equal(pts.view(np.uint64), np.ascontiguousarray(g("pts_cam")).view(np.uint64)) or \
+        np.array_equal(pts, g("pts_cam"), equal_nan=True)
+    assert np.array_equal(pix, g("pix"))
+    assert np.array_equal(vis, g("vis"))
+
+
+@pytest.mark.parametrize("n", [20_000, 200_000, 1_000_000])
+def test_blas_order_is_fma_chain_on_this_host(n):
+    """NumPy's dgemm on this host (both the small-matrix and the blocked path) == fma chain."""
+    rng = np.random.default_rng(n)
+    xyz = rng.uniform(-6, 6, (n, 3))
+    pose = np.eye(4)
+    a = 0.7
+    pose[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+    pose[:3, 3] = [1.5, -2.25, 1.4]
+    inv = np.linalg.inv(pose)
+    k33 = np.array([[1170.187988, 0.0, 647.75], [0.0, 1170.187988, 483.75], [0.0, 0.0, 1.0]])
+    pts = pref.world_to_camera_inv(pref.homogeneous_cloud(xyz), inv)
+    pix = pref.project_to_pixels(pts, k33)
+    depth = np.zeros((4, 4), np.float32)
+    cpts, cpix, _ = geom_fma.view(xyz, inv, k33, depth)
+    assert np.array_equal(pts, cpts)
+    assert np.array_equal(pix, cpix)
+
+
+def test_aggregation_helpers():
+    z = Z("agg_helpers.npz")
+    for case in [str(c) for c in z["cases"]]:
+        g = lambda k: z[f"{case}.{k}"]
+        n = int(g("n"))
+        ins = torch.from_numpy(gio.unpack_bool_rows(g("ins"), n))
+        if case.startswith("ovl_"):
+            groups = [list(range(s)) for s in g("sizes")]
+            res = pref.resolve_overlaps(ins.clone(), groups)
+            assert np.array_equal(gio.pack_bool_rows(res.numpy()), g("resolved")), case
+            continue
+        labels = [str(s) for s in g("labels")]
+        conf = torch.from_numpy(g("conf").copy())
+        if str(g("conf_dtype")) == "torch.float16":
+            conf = conf.half()
+        assert np.array_equal(pref.label_equality(labels).numpy(), g("sim")), case
+        iou = pref.pairwise_iou(ins)
+        assert np.array_equal(iou.numpy().view(np.uint32), g("iou_bits")), case
+        merge = pref.label_equality(labels) & (iou > 0.2)
+        assert np.array_equal(merge.numpy(), g("merge")), case
+        assert pref.connected_groups(merge.float()) == gio.loads_groups(g("components")), case
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            agg, groups = pref.aggregate({"ins": ins, "conf": conf, "final_class": labels}, 0.2,
+                                         int(g("min_members")))
+        assert groups == gio.loads_groups(g("groups")), case
+        exp = {k: z[f"{case}.agg.{k}"] for k in ("kind", "ins_packed", "k", "conf", "conf_dtype", "final_class")}
+        got = gio.result_to_arrays(agg, n)
+        assert str(got["kind"]) == str(exp["kind"]), case
+        assert np.array_equal(got["ins_packed"], exp["ins_packed"]), case
+        assert np.array_equal(got["conf"], exp["conf"]) and str(got["conf_dtype"]) == str(exp["conf_dtype"]), case
+        assert list(got["final_class"]) == list(exp["final_class"]), case
+
+
+def test_refinement_helpers():
+    z = Z("refine_helpers.npz")
+    rles = gio.unpack_rles(z["rle1d.len"], z["rle1d.counts"], z["rle1d.offs"])
+    for i, r in enumerate(rles):
+        assert np.array_equal(rle_ref.rle_decode_ref(r), z[f"rle1d.dec{i}"])
+    dense = torch.from_numpy(z["rlebatch.dense"])
+    enc = rle_ref.rle_encode_batch_ref(dense)
+    exp = gio.unpack_rles(z["rlebatch.len"], z["rlebatch.counts"], z["rlebatch.offs"])
+    assert all(a["length"] == b["length"] and np.array_equal(a["counts"], b["counts"]) for a, b in zip(enc, exp))
+    assert torch.equal(rle_ref.rle_decode_batch_ref(enc).bool(), dense)
+    m2 = torch.from_numpy(z["rle2d.dense"])
+    fr = rle_ref.encode_2d_masks_ref([{"segmented_frame_masks": m2.clone()}])
+    exp = gio.unpack_rles(z["rle2d.len"], z["rle2d.counts"], z["rle2d.offs"])
+    assert all(np.array_equal(a["counts"], b["counts"]) for a, b in zip(fr[0]["segmented_frame_masks"], exp))
+    back = rle_ref.decode_2d_masks_ref(fr, (6, 9))[0]["segmented_frame_masks"]
+    assert back.dtype == torch.uint8 and torch.equal(back.bool(), m2)
+    s1, s2 = torch.from_numpy(z["stages.s1"]), torch.from_numpy(z["stages.s2"])
+    assert np.array_equal(rref.iou_between_stages(s1, s2).numpy().view(np.uint32), z["stages.iou_bits"])
+    assert np.array_equal(rref.iou_between_stages(s1, s1).numpy().view(np.uint32), z["stages.self_iou_bits"])
+    for tag, dt in (("f32", torch.float32), ("f16", torch.float16)):
+        emb = torch.from_numpy(z[f"clip.emb_{tag}"]).to(dt)
+        sims = np.array([[rref.text_cosine(lambda t: emb[int(t[1:])], f"a{a}", f"b{b}") for b in range(6)]
+                         for a in range(6)])
+        assert np.array_equal(sims, z[f"clip.sims_{tag}"])
+    with open(os.path.join(gio.GOLDEN_DIR, "scannet200_labels.json")) as f:
+        labels = json.load(f)
+    assert labels == rref.SCANNET200
+    from beyond_fixed_forms_amd.labels import SCANNET200_LABELS
+    assert labels == SCANNET200_LABELS
+
+
+def _check_result(got, z, prefix, n):
+    g = gio.result_to_arrays(got, n)
+    for k in ("kind", "conf_dtype"):
+        assert str(g[k]) == str(z[f"{prefix}.{k}"]), (prefix, k)
+    assert np.array_equal(g["ins_packed"], z[f"{prefix}.ins_packed"]), prefix
+    assert np.array_equal(g["conf"], z[f"{prefix}.conf"]), prefix
+    assert list(g["final_class"]) == list(z[f"{prefix}.final_class"]), prefix
+
+
+@pytest.mark.parametrize("name", ["scene_tiny_seed0", "scene_tiny_seed1", "scene_tiny_seed2", "scene_c1_seed0"])
+def test_whole_scene(name):
+    from beyond_fixed_forms_amd.config import Config
+    from oracle.make_golden_shared import bank_encoder
+    from beyond_fixed_forms_amd.synthetic import make_text_bank
+    z = Z(name + ".npz")
+    scene = gio.scene_from_arrays(z)
+    cfg = Config.with_defaults(width_2d=scene.width, height_2d=scene.height)
+    n = scene.points.shape[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, dbg = pref.project_scene_ref(scene, cfg, return_debug=True)
+    _check_result(res, z, "stage2", n)
+    assert dbg["groups"] == gio.loads_groups(z["dbg.groups"])
+    assert np.array_equal(np.array(np.float32(dbg["thr"])).view(np.uint32), z["dbg.thr_bits"])
+    bank, index = make_text_bank(int(z["bank_dim"]), seed=int(z["bank_seed"]))
+    fin = rref.refine_class_ref([(scene.scene_id, scene.stage1, res)], cfg, "table", bank_encoder(bank.float(), index))
+    _check_result(fin[scene.scene_id], z, "final", n)
