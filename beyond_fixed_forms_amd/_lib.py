@@ -1,0 +1,237 @@
+"""ctypes binding of libbff_hip.so (C ABI: include/bff_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call is rejected this raises.
+Tensors are passed as raw device pointers; the launch stream is torch's current stream, so torch
+events and torch ops order correctly around the kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbff_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+_P, _I, _L, _D, _F = c_void_p, c_int32, c_int64, c_double, c_float
+
+# name -> argument ctypes (every entry point returns int); mirrors include/bff_hip.h one to one
+SIGNATURES = {
+    "bff_rle_to_maskbits": [_P, _P, _P, _P, _I, _L, _I, _P, _P],
+    "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P],
+    "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
+    "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
+    "bff_merge_adjacency": [_P, _I, _L, _P, _P, _F, _P, _P, _P],
+    "bff_components_round": [_P, _I, _P, _P, _P, _P],
+    "bff_or_reduce_groups": [_P, _L, _P, _P, _I, _P, _P],
+    "bff_group_conf_mean": [_P, _I, _P, _P, _I, _P, _P],
+    "bff_apply_row_ops": [_P, _L, _P, _I, _P],
+    "bff_and_rows": [_P, _I, _L, _P, _P],
+    "bff_gather_rows": [_P, _P, _I, _L, _P, _P],
+    "bff_unpack_rows": [_P, _I, _L, _L, _P, _P],
+    "bff_pack_rows": [_P, _I, _L, _L, _P, _P],
+    "bff_rle_to_rows": [_P, _P, _P, _I, _L, _L, _P, _P],
+    "bff_count_lattice": [_P, _P, _L, _I, _I, _P, _P],
+    "bff_ratio_keep": [_P, _P, _L, _F, _I, _L, _P, _P],
+    "bff_cosine_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
+}
+PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, [])}
+ABI_VERSION = 1
+
+
+class BffLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libbff_hip.so once; raise BffLibraryError (never fall back) if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BffLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C {CSRC_DIR}` (or __graft_entry__.build()). "
+            "This package has no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise BffLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = args, c_int32
+    for name, (res, args) in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = args, res
+    if lib.bff_abi_version() != ABI_VERSION:
+        raise BffLibraryError(f"{LIB_PATH}: ABI {lib.bff_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("bff kernels take device tensors (no CPU path)")
+    if not t.is_contiguous():
+        raise ValueError("bff kernels take contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    return c_void_p(t.data_ptr())
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args, _stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.bff_last_error().decode()}")
+
+
+i32, i64, f32, f64, u8 = torch.int32, torch.int64, torch.float32, torch.float64, torch.uint8
+
+
+# ------------------------------------------------------------------ typed wrappers
+def rle_to_maskbits(run_start, run_end, mask_run_offs, view_mask_offs, n_views, n_pixels, word_bits, maskbits):
+    call("bff_rle_to_maskbits", _ptr(run_start, i32), _ptr(run_end, i32), _ptr(mask_run_offs, i32),
+         _ptr(view_mask_offs, i32), n_views, n_pixels, word_bits,
+         _ptr(maskbits, torch.int32 if word_bits == 32 else torch.int64))
+
+
+def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, height, width, depth_thresh,
+                  maskbits, word_bits, frame_mask, frame_rowbase, frame_nmask, frame_flags,
+                  rows, masked_count, viewed_count):
+    k = (c_double * 9)(*[float(v) for v in cam_intr.reshape(-1)])
+    n_frames = inv_pose.shape[0]
+    nw = (n_points + 63) // 64
+    call("bff_project_views", _ptr(xyz_soa, f64), n_points, xyz_soa.shape[1], _ptr(inv_pose, f64),
+         ctypes.cast(k, c_void_p), n_frames, _ptr(depth, f32), _ptr(depth_index, i32), height, width,
+         float(depth_thresh), _ptr(maskbits), word_bits, _ptr(frame_mask, i32), _ptr(frame_rowbase, i32),
+         _ptr(frame_nmask, i32), _ptr(frame_flags, i32), _ptr(rows, i64),
+         0 if rows is None else rows.shape[0], nw, _ptr(masked_count, i32), _ptr(viewed_count, i32))
+
+
+def popcount_rows(rows, idx=None):
+    n = rows.shape[0] if idx is None else idx.shape[0]
+    area = torch.empty(n, dtype=i32, device=rows.device)
+    call("bff_popcount_rows", _ptr(rows, i64), _ptr(idx, i32), n, rows.shape[1], _ptr(area))
+    return area
+
+
+def cross_popcount(a, b, ia=None, ib=None):
+    na = a.shape[0] if ia is None else ia.shape[0]
+    nb = b.shape[0] if ib is None else ib.shape[0]
+    out = torch.empty((na, nb), dtype=i32, device=a.device)
+    call("bff_cross_popcount", _ptr(a, i64), _ptr(ia, i32), na, _ptr(b, i64), _ptr(ib, i32), nb, a.shape[1], _ptr(out))
+    return out
+
+
+def merge_adjacency(rows, area, label_id, iou_thres, want_inter=False):
+    n = rows.shape[0]
+    aw = (n + 63) // 64
+    adj = torch.empty((n, aw), dtype=i64, device=rows.device)
+    inter = torch.empty((n, n), dtype=i32, device=rows.device) if want_inter else None
+    call("bff_merge_adjacency", _ptr(rows, i64), n, rows.shape[1], _ptr(area, i32), _ptr(label_id, i32),
+         float(iou_thres), _ptr(adj), _ptr(inter))
+    return (adj, inter) if want_inter else adj
+
+
+def components(adj, max_rounds=10_000):
+    """label[i] = smallest index of i's connected component (iterates bff_components_round)."""
+    n = adj.shape[0]
+    a = torch.arange(n, dtype=i32, device=adj.device)
+    b = torch.empty_like(a)
+    changed = torch.zeros(1, dtype=i32, device=adj.device)
+    for _ in range(max_rounds):
+        changed.zero_()
+        call("bff_components_round", _ptr(adj, i64), n, _ptr(a), _ptr(b), _ptr(changed))
+        a, b = b, a
+        if int(changed.item()) == 0:
+            return a
+    raise RuntimeError("bff_components_round did not converge")
+
+
+def or_reduce_groups(rows, group_offs, members):
+    k = group_offs.shape[0] - 1
+    out = torch.empty((k, rows.shape[1]), dtype=i64, device=rows.device)
+    call("bff_or_reduce_groups", _ptr(rows, i64), rows.shape[1], _ptr(group_offs, i32), _ptr(members, i32), k, _ptr(out))
+    return out
+
+
+def group_conf_mean(conf, group_offs, members):
+    if conf.dtype not in (torch.float16, torch.float32):
+        raise TypeError(f"confidences must be float16 or float32, got {conf.dtype}")
+    k = group_offs.shape[0] - 1
+    out = torch.empty(k, dtype=conf.dtype, device=conf.device)
+    call("bff_group_conf_mean", _ptr(conf), 1 if conf.dtype == torch.float16 else 0, _ptr(group_offs, i32),
+         _ptr(members, i32), k, _ptr(out))
+    return out
+
+
+def apply_row_ops(rows, ops):
+    call("bff_apply_row_ops", _ptr(rows, i64), rows.shape[1], _ptr(ops, i32), ops.shape[0])
+
+
+def and_rows(rows, keep):
+    call("bff_and_rows", _ptr(rows, i64), rows.shape[0], rows.shape[1], _ptr(keep, i64))
+
+
+def gather_rows(rows, idx):
+    out = torch.empty((idx.shape[0], rows.shape[1]), dtype=i64, device=rows.device)
+    call("bff_gather_rows", _ptr(rows, i64), _ptr(idx, i32), idx.shape[0], rows.shape[1], _ptr(out))
+    return out
+
+
+def unpack_rows(rows, n_points):
+    dense = torch.empty((rows.shape[0], n_points), dtype=torch.bool, device=rows.device)
+    call("bff_unpack_rows", _ptr(rows, i64), rows.shape[0], rows.shape[1], n_points, _ptr(dense))
+    return dense
+
+
+def pack_rows(dense):
+    if dense.dtype not in (torch.bool, torch.uint8):
+        raise TypeError("pack_rows takes bool/uint8 rows")
+    n = dense.shape[1]
+    nw = (n + 63) // 64
+    rows = torch.empty((dense.shape[0], nw), dtype=i64, device=dense.device)
+    call("bff_pack_rows", _ptr(dense), dense.shape[0], n, nw, _ptr(rows))
+    return rows
+
+
+def rle_to_rows(run_start, run_end, row_run_offs, n_points):
+    k = row_run_offs.shape[0] - 1
+    nw = (n_points + 63) // 64
+    rows = torch.empty((k, nw), dtype=i64, device=run_start.device)
+    call("bff_rle_to_rows", _ptr(run_start, i32), _ptr(run_end, i32), _ptr(row_run_offs, i32), k, n_points, nw, _ptr(rows))
+    return rows
+
+
+def count_lattice(masked, viewed, m_max, v_max):
+    presence = torch.zeros((m_max + 1) * (v_max + 1), dtype=u8, device=masked.device)
+    call("bff_count_lattice", _ptr(masked, i32), _ptr(viewed, i32), masked.shape[0], m_max, v_max, _ptr(presence))
+    return presence
+
+
+def ratio_keep(masked, viewed, thr, use_thr):
+    n = masked.shape[0]
+    nw = (n + 63) // 64
+    keep = torch.empty(nw, dtype=i64, device=masked.device)
+    call("bff_ratio_keep", _ptr(masked, i32), _ptr(viewed, i32), n, float(thr), int(bool(use_thr)), nw, _ptr(keep))
+    return keep
+
+
+def cosine_gemm_f16(a, b):
+    if a.dtype != torch.float16 or b.dtype != torch.float16:
+        raise TypeError("cosine_gemm_f16 takes float16 operands")
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=f32, device=a.device)
+    call("bff_cosine_gemm_f16", _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], _ptr(out))
+    return out

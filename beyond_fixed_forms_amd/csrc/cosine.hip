@@ -1,0 +1,70 @@
+// Cosine-similarity GEMM on the matrix cores (include/bff_hip.h: a21, a24).
+//
+// cos[i][j] = <a_i, b_j> / (|a_i| |b_j|) for f16 rows a (na x dim) and b (nb x dim), f32 accumulate.
+// One wave owns a 16x16 output tile and walks dim in steps of 32 with v_mfma_f32_16x16x32_f16; both
+// operands are row-major along k, so each lane's 8-element fragment is one 16-byte load and no LDS
+// staging is needed (the problem is a few GFLOP at most: 200 labels x 768 dims x <= 10^4 features).
+// Row norms are accumulated from the same fragments.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace bff {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using float4v = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(256) void cosine_gemm_f16_kernel(const _Float16 *__restrict__ a, int na,
+                                                               const _Float16 *__restrict__ b, int nb, int dim,
+                                                               float *__restrict__ out)
+{
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int tile_j = blockIdx.x * 4 + wave;                 // 4 column tiles per block
+    const int i0 = blockIdx.y * 16, j0 = tile_j * 16;
+    if (j0 >= nb) return;                                     // wave-uniform
+    const int r = lane & 15, kq = lane >> 4;                  // fragment: row/col r, k = 8*kq .. 8*kq+7
+    const bool ra = i0 + r < na, rb = j0 + r < nb;
+    const _Float16 *pa = a + (int64_t)(ra ? i0 + r : 0) * dim + 8 * kq;
+    const _Float16 *pb = b + (int64_t)(rb ? j0 + r : 0) * dim + 8 * kq;
+    float4v acc = {0.f, 0.f, 0.f, 0.f};
+    float sa = 0.f, sb = 0.f;
+    const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k0 = 0; k0 < dim; k0 += 32) {
+        const half8 fa = ra ? *reinterpret_cast<const half8 *>(pa + k0) : zero;
+        const half8 fb = rb ? *reinterpret_cast<const half8 *>(pb + k0) : zero;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (float)fa[e], y = (float)fb[e];
+            sa = fmaf(x, x, sa);
+            sb = fmaf(y, y, sb);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc, 0, 0, 0);
+    }
+    // the four k-quarters of a row live in lanes r, r+16, r+32, r+48
+    sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);
+    sb += __shfl_xor(sb, 16); sb += __shfl_xor(sb, 32);
+    const float nbj = sqrtf(sb);                              // column j0 + (lane & 15)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = kq * 4 + q;                           // C/D map: col = lane & 15, row = 4*(lane>>4) + q
+        const float nai = sqrtf(__shfl(sa, row));
+        const int i = i0 + row, j = j0 + r;
+        if (i < na && j < nb) out[(int64_t)i * nb + j] = acc[q] / (nai * nbj);
+    }
+}
+
+}  // namespace bff
+
+using namespace bff;
+
+extern "C" int bff_cosine_gemm_f16(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim, float *cos,
+                                   void *stream)
+{
+    BFF_REQUIRE(na >= 0 && nb >= 0 && dim > 0, "bff_cosine_gemm_f16: bad sizes");
+    BFF_REQUIRE(dim % 32 == 0, "bff_cosine_gemm_f16: dim must be a multiple of 32");
+    if (na == 0 || nb == 0) return BFF_OK;
+    BFF_REQUIRE(a && b && cos, "bff_cosine_gemm_f16: null pointer");
+    dim3 grid((unsigned)ceil_div(ceil_div(nb, 16), 4), (unsigned)ceil_div(na, 16));
+    cosine_gemm_f16_kernel<<<grid, 256, 0, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b, nb, dim, cos);
+    return launched("bff_cosine_gemm_f16");
+}

@@ -1,0 +1,258 @@
+// Per-frame projection sweep and 2-D RLE decode (include/bff_hip.h: a1, a2-a7, a15).
+//
+// Data layout in HBM
+//   xyz        f64 [3][n_pad]            structure of arrays: a wave reads 3 x 512 B contiguous
+//   depth      f32 [n_depth][H*W]        gathered at the projected pixel (4 B / visible point)
+//   maskbits   u32|u64 [n_mviews][H*W]   bit b = mask b of that frame covers the pixel (one gather
+//                                         returns all masks of the frame)
+//   rows       u64 [n_rows][nw]          instance bit rows: a wave's 64 points are exactly one word,
+//                                         so __ballot() of "bit b set" IS the output word
+// Kernel shape: 256 threads = 4 waves own 1024 consecutive points (16 row words = 128 B per row,
+// one full line per row store), 4 points per thread kept in registers across the frames of the
+// block's frame tile; pose and intrinsics are wave-uniform (scalar loads / kernel arguments).
+#include "common.h"
+
+namespace bff {
+
+constexpr int kBlock = 256;
+constexpr int kPPT = 4;                          // points per thread
+constexpr int kWordsPerBlock = (kBlock / kWave) * kPPT;   // 16 row words per block
+constexpr int kPtsPerBlock = kWordsPerBlock * kWave;       // 1024
+
+struct Intrinsics { double k[9]; };
+
+template <typename WordT>
+__global__ __launch_bounds__(kBlock) void project_views_kernel(
+    const double *__restrict__ xyz, int64_t n_points, int64_t n_pad,
+    const double *__restrict__ inv_pose, Intrinsics K, int n_frames, int frames_per_block,
+    const float *__restrict__ depth, const int32_t *__restrict__ depth_index, int H, int W, double thresh,
+    const WordT *__restrict__ maskbits, const int32_t *__restrict__ frame_mask,
+    const int32_t *__restrict__ frame_rowbase, const int32_t *__restrict__ frame_nmask,
+    const int32_t *__restrict__ frame_flags,
+    uint64_t *__restrict__ rows, int64_t nw, int32_t *__restrict__ masked_count,
+    int32_t *__restrict__ viewed_count)
+{
+    // [bit][word] staging of the block's row words; pitch 17 keeps lane-strided writes off one bank
+    __shared__ uint64_t stage[sizeof(WordT) * 8][kWordsPerBlock + 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t word0 = (int64_t)blockIdx.x * kWordsPerBlock;
+    const int64_t hw = (int64_t)H * W;
+
+    double px[kPPT], py[kPPT], pz[kPPT];
+    bool valid[kPPT];
+    int mcount[kPPT], vcount[kPPT];
+#pragma unroll
+    for (int j = 0; j < kPPT; ++j) {
+        const int64_t n = (word0 + wave + 4 * j) * kWave + lane;
+        valid[j] = n < n_points;
+        const int64_t m = valid[j] ? n : 0;
+        px[j] = xyz[m];
+        py[j] = xyz[n_pad + m];
+        pz[j] = xyz[2 * n_pad + m];
+        mcount[j] = 0;
+        vcount[j] = 0;
+    }
+
+    const int f0 = blockIdx.y * frames_per_block;
+    const int f1 = min(n_frames, f0 + frames_per_block);
+    const double dW = (double)W, dH = (double)H;
+    for (int f = f0; f < f1; ++f) {
+        const double *P = inv_pose + 16 * (int64_t)f;
+        const float *dimg = depth + (int64_t)depth_index[f] * hw;
+        const int mi = maskbits ? frame_mask[f] : -1;
+        const WordT *mimg = mi >= 0 ? maskbits + (int64_t)mi * hw : nullptr;
+        const int nm = mimg ? frame_nmask[f] : 0;
+        const bool count_viewed = (frame_flags[f] & 1) != 0;
+#pragma unroll
+        for (int j = 0; j < kPPT; ++j) {
+            // k-ascending fma chains from +0.0: bit-identical to the reference's dgemm (header contract)
+            const double cx = fma(P[3], 1.0, fma(P[2], pz[j], fma(P[1], py[j], fma(P[0], px[j], 0.0))));
+            const double cy = fma(P[7], 1.0, fma(P[6], pz[j], fma(P[5], py[j], fma(P[4], px[j], 0.0))));
+            const double cz = fma(P[11], 1.0, fma(P[10], pz[j], fma(P[9], py[j], fma(P[8], px[j], 0.0))));
+            const double p0 = fma(K.k[2], cz, fma(K.k[1], cy, fma(K.k[0], cx, 0.0)));
+            const double p1 = fma(K.k[5], cz, fma(K.k[4], cy, fma(K.k[3], cx, 0.0)));
+            const double u = rint(p0 / cz);
+            const double v = rint(p1 / cz);
+            const bool inb = valid[j] && (u >= 0.0) && (u < dW) && (v >= 0.0) && (v < dH);   // NaN fails
+            bool vis = false;
+            WordT w = 0;
+            if (inb) {
+                const int64_t pix = (int64_t)(int)v * W + (int)u;
+                const float d = dimg[pix];
+                vis = (d != 0.0f) && (fabs(cz - (double)d) < thresh);
+                if (vis && mimg) w = mimg[pix];
+            }
+            if (count_viewed) vcount[j] += vis ? 1 : 0;
+            if (mimg) {
+                mcount[j] += (sizeof(WordT) == 8) ? __popcll((uint64_t)w) : __popc((uint32_t)w);
+                uint64_t mine = 0;
+                for (int b = 0; b < nm; ++b) {            // nm is wave-uniform
+                    const uint64_t bal = __ballot((w >> b) & 1);
+                    if (lane == b) mine = bal;
+                }
+                if (lane < nm) stage[lane][wave + 4 * j] = mine;
+            }
+        }
+        if (mimg) {                                        // block-uniform
+            __syncthreads();
+            const int64_t rb = frame_rowbase[f];
+            const int wd = tid & (kWordsPerBlock - 1);
+            if (word0 + wd < nw)
+                for (int b = tid / kWordsPerBlock; b < nm; b += kBlock / kWordsPerBlock)
+                    rows[(rb + b) * nw + word0 + wd] = stage[b][wd];
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kPPT; ++j) {
+        const int64_t n = (word0 + wave + 4 * j) * kWave + lane;
+        if (valid[j]) {
+            if (masked_count && mcount[j]) atomicAdd(masked_count + n, mcount[j]);
+            if (viewed_count && vcount[j]) atomicAdd(viewed_count + n, vcount[j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2-D RLE -> mask words.  One block walks a band of `kChunksPerBand` chunks of one mask-view; thread
+// b < n_masks keeps a cursor into mask b's (sorted, disjoint) run list.  Per chunk the runs are
+// entered as XOR toggles at their clipped start and end in LDS, an XOR prefix scan turns toggles
+// into coverage, and the chunk is written once, coalesced.  HBM traffic = one write of the image.
+constexpr int kChunk = 2048;                 // pixels per chunk (8 per thread)
+constexpr int kChunksPerBand = 16;
+
+template <typename WordT>
+__global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
+    const int32_t *__restrict__ run_start, const int32_t *__restrict__ run_end,
+    const int32_t *__restrict__ mask_run_offs, const int32_t *__restrict__ view_mask_offs,
+    int64_t n_pixels, WordT *__restrict__ maskbits)
+{
+    __shared__ WordT bits[kChunk];
+    __shared__ WordT wave_tot[kBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int v = blockIdx.y;
+    const int g0 = view_mask_offs[v];
+    const int nm = view_mask_offs[v + 1] - g0;
+    const int64_t band0 = (int64_t)blockIdx.x * kChunk * kChunksPerBand;
+    WordT *img = maskbits + (int64_t)v * n_pixels;
+
+    int cur = 0, hi = 0;
+    if (tid < nm) {
+        int lo = mask_run_offs[g0 + tid];
+        hi = mask_run_offs[g0 + tid + 1];
+        int r = hi;                                   // first run with end > band0
+        while (lo < r) {
+            const int mid = (lo + r) >> 1;
+            if ((int64_t)run_end[mid] > band0) r = mid; else lo = mid + 1;
+        }
+        cur = r;
+    }
+    for (int c = 0; c < kChunksPerBand; ++c) {
+        const int64_t c0 = band0 + (int64_t)c * kChunk;
+        if (c0 >= n_pixels) break;
+        const int64_t c1 = min(c0 + kChunk, n_pixels);
+#pragma unroll
+        for (int k = 0; k < kChunk / kBlock; ++k) bits[tid + k * kBlock] = 0;
+        __syncthreads();
+        if (tid < nm) {
+            const WordT bit = (WordT)1 << tid;
+            while (cur < hi) {
+                const int64_t s = run_start[cur], e = run_end[cur];
+                if (s >= c1) break;
+                const int ls = (int)(max(s, c0) - c0);
+                atomicXor(&bits[ls], bit);
+                if (e < c1) atomicXor(&bits[(int)(e - c0)], bit);
+                if (e > c1) break;                    // run continues into the next chunk
+                ++cur;
+            }
+        }
+        __syncthreads();
+        // XOR prefix scan: 8 consecutive words per thread, wave scan of the thread totals
+        WordT loc[kChunk / kBlock];
+        WordT acc = 0;
+#pragma unroll
+        for (int k = 0; k < kChunk / kBlock; ++k) { acc ^= bits[tid * (kChunk / kBlock) + k]; loc[k] = acc; }
+        WordT incl = acc;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const WordT up = __shfl_up(incl, d);
+            if (lane >= d) incl ^= up;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = incl;
+        __syncthreads();
+        WordT carry = incl ^ acc;                     // exclusive prefix within the wave
+        for (int q = 0; q < wave; ++q) carry ^= wave_tot[q];
+#pragma unroll
+        for (int k = 0; k < kChunk / kBlock; ++k) bits[tid * (kChunk / kBlock) + k] = loc[k] ^ carry;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kChunk / kBlock; ++k) {
+            const int64_t p = c0 + tid + k * kBlock;
+            if (p < c1) img[p] = bits[tid + k * kBlock];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace bff
+
+using namespace bff;
+
+extern "C" int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const int32_t *mask_run_offs,
+                                   const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels,
+                                   int32_t word_bits, void *maskbits, void *stream)
+{
+    BFF_REQUIRE(n_views >= 0 && n_pixels > 0, "bff_rle_to_maskbits: bad sizes");
+    BFF_REQUIRE(word_bits == 32 || word_bits == 64, "bff_rle_to_maskbits: word_bits must be 32 or 64");
+    BFF_LIMIT(n_pixels < (1ll << 31), "bff_rle_to_maskbits: image larger than 2^31 pixels");
+    if (n_views == 0) return BFF_OK;
+    BFF_REQUIRE(mask_run_offs && view_mask_offs && maskbits, "bff_rle_to_maskbits: null pointer");   // run arrays may be empty (NULL)
+    dim3 grid((unsigned)ceil_div(n_pixels, (int64_t)kChunk * kChunksPerBand), (unsigned)n_views);
+    if (word_bits == 32)
+        rle_to_maskbits_kernel<uint32_t><<<grid, kBlock, 0, as_stream(stream)>>>(
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits);
+    else
+        rle_to_maskbits_kernel<uint64_t><<<grid, kBlock, 0, as_stream(stream)>>>(
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits);
+    return launched("bff_rle_to_maskbits");
+}
+
+extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
+                                 const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
+                                 const float *depth, const int32_t *depth_index, int32_t height, int32_t width,
+                                 double depth_thresh,
+                                 const void *maskbits, int32_t word_bits,
+                                 const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
+                                 const int32_t *frame_flags,
+                                 uint64_t *rows, int64_t n_rows, int64_t nw,
+                                 int32_t *masked_count, int32_t *viewed_count, void *stream)
+{
+    BFF_REQUIRE(n_points >= 0 && n_pad >= n_points && n_frames >= 0, "bff_project_views: bad sizes");
+    BFF_REQUIRE(height > 0 && width > 0, "bff_project_views: bad image size");
+    BFF_LIMIT((int64_t)height * width < (1ll << 31), "bff_project_views: image larger than 2^31 pixels");
+    if (n_points == 0 || n_frames == 0) return BFF_OK;
+    BFF_REQUIRE(xyz && inv_pose && cam_intr_host && depth && depth_index && frame_flags, "bff_project_views: null pointer");
+    BFF_REQUIRE(nw == ceil_div(n_points, 64), "bff_project_views: nw must be ceil(n_points/64)");
+    if (maskbits) {
+        BFF_REQUIRE(word_bits == 32 || word_bits == 64, "bff_project_views: word_bits must be 32 or 64");
+        BFF_REQUIRE(frame_mask && frame_rowbase && frame_nmask && rows && n_rows >= 0, "bff_project_views: mask frames need row outputs");
+    }
+    Intrinsics K;
+    for (int i = 0; i < 9; ++i) K.k[i] = cam_intr_host[i];
+    const int64_t gx = ceil_div(n_points, kPtsPerBlock);
+    int fpb = (int)((int64_t)n_frames * gx / 4096);      // keep >= ~4096 blocks in flight
+    fpb = fpb < 1 ? 1 : (fpb > 8 ? 8 : fpb);
+    dim3 grid((unsigned)gx, (unsigned)ceil_div(n_frames, fpb));
+    if (!maskbits || word_bits == 32)
+        project_views_kernel<uint32_t><<<grid, kBlock, 0, as_stream(stream)>>>(
+            xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
+            (const uint32_t *)maskbits, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
+            masked_count, viewed_count);
+    else
+        project_views_kernel<uint64_t><<<grid, kBlock, 0, as_stream(stream)>>>(
+            xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
+            (const uint64_t *)maskbits, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
+            masked_count, viewed_count);
+    return launched("bff_project_views");
+}

@@ -1,0 +1,392 @@
+// Bit-row primitives (include/bff_hip.h: a8-a13, a16-a20).
+//
+// A boolean row over N points is nw = ceil(N/64) uint64 words.  Set algebra on rows is AND/OR/
+// ANDNOT on words, cardinalities are popcounts, the {0,1} matmuls of the reference
+// (F @ F.T, projection_2d_to_3d.py:159; mask_1 @ mask_2.T, refinement.py:84) are
+// popcount(a & b) accumulated over words -- exact integers, 1/32 of the bytes of the float form.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace bff {
+
+constexpr int kT = 64;        // tile of 64 x 64 row pairs per 256-thread block
+constexpr int kKW = 32;       // words staged per step
+constexpr int kPitch = kT + 1;
+
+// ---- popcount of rows -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void popcount_rows_kernel(const uint64_t *__restrict__ rows,
+                                                             const int32_t *__restrict__ idx, int64_t nw,
+                                                             int32_t *__restrict__ area)
+{
+    __shared__ int part[4];
+    const int r = blockIdx.x;
+    const uint64_t *row = rows + (int64_t)(idx ? idx[r] : r) * nw;
+    int s = 0;
+    for (int64_t w = threadIdx.x; w < nw; w += blockDim.x) s += popc64(row[w]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+    if (lane_id() == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) area[r] = part[0] + part[1] + part[2] + part[3];
+}
+
+// ---- 64x64 tile of popcount(a_i & b_j) -------------------------------------------------------
+// LDS images are [word][row] (pitch 65) so that the 4 rows / 4 columns a thread needs for one word
+// are 32 contiguous bytes; thread (ti, tj) of the 16 x 16 thread grid owns rows 4ti..4ti+3 and
+// columns 4tj..4tj+3.
+__device__ __forceinline__ void tile_popcount(const uint64_t *__restrict__ a, const int32_t *__restrict__ ia,
+                                              int na, int i0, const uint64_t *__restrict__ b,
+                                              const int32_t *__restrict__ ib, int nb, int j0, int64_t nw,
+                                              uint64_t (*sa)[kPitch], uint64_t (*sb)[kPitch], int acc[4][4])
+{
+    const int tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
+    const int lk = tid & (kKW - 1), lr = tid >> 5;          // loader: word lk of rows lr, lr+8, ...
+    const uint64_t *pa[8];
+    const uint64_t *pb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int ra = i0 + lr + 8 * q, rb = j0 + lr + 8 * q;
+        pa[q] = ra < na ? a + (int64_t)(ia ? ia[ra] : ra) * nw : nullptr;
+        pb[q] = rb < nb ? b + (int64_t)(ib ? ib[rb] : rb) * nw : nullptr;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+    for (int64_t k0 = 0; k0 < nw; k0 += kKW) {
+        const bool kin = k0 + lk < nw;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sa[lk][lr + 8 * q] = (kin && pa[q]) ? pa[q][k0 + lk] : 0;
+            sb[lk][lr + 8 * q] = (kin && pb[q]) ? pb[q][k0 + lk] : 0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < kKW; ++kk) {
+            uint64_t av[4], bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { av[r] = sa[kk][ti * 4 + r]; bv[r] = sb[kk][tj * 4 + r]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] += popc64(av[r] & bv[c]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__restrict__ a,
+                                                              const int32_t *__restrict__ ia, int na,
+                                                              const uint64_t *__restrict__ b,
+                                                              const int32_t *__restrict__ ib, int nb, int64_t nw,
+                                                              int32_t *__restrict__ inter)
+{
+    __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
+    int acc[4][4];
+    const int i0 = blockIdx.y * kT, j0 = blockIdx.x * kT;
+    tile_popcount(a, ia, na, i0, b, ib, nb, j0, nw, sa, sb, acc);
+    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = i0 + ti * 4 + r, j = j0 + tj * 4 + c;
+            if (i < na && j < nb) inter[(int64_t)i * nb + j] = acc[r][c];
+        }
+}
+
+// Upper-triangular tile pairs of the symmetric Gram matrix; the epilogue applies the reference's
+// float32 IoU test and emits adjacency words for the tile and its mirror image.
+__global__ __launch_bounds__(256) void merge_adjacency_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
+                                                               const int32_t *__restrict__ area,
+                                                               const int32_t *__restrict__ label_id, float thr,
+                                                               uint64_t *__restrict__ adj, int aw,
+                                                               int32_t *__restrict__ inter, int n_tiles)
+{
+    __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
+    __shared__ uint8_t flag[kT][kT + 4];
+    // linear upper-triangular index -> (bi <= bj)
+    int t = blockIdx.x, bi = 0;
+    while (t >= n_tiles - bi) { t -= n_tiles - bi; ++bi; }
+    const int bj = bi + t;
+    const int i0 = bi * kT, j0 = bj * kT;
+    int acc[4][4];
+    tile_popcount(rows, nullptr, n, i0, rows, nullptr, n, j0, nw, sa, sb, acc);
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = i0 + ti * 4 + r, j = j0 + tj * 4 + c;
+            bool ok = false;
+            if (i < n && j < n) {
+                const float fi = (float)acc[r][c];
+                const float uni = (float)area[i] + (float)area[j] - fi;
+                const float iou = __fdiv_rn(fi, uni);           // 0/0 -> NaN -> compares false
+                ok = (label_id[i] == label_id[j]) && (iou > thr);
+                if (inter) {
+                    inter[(int64_t)i * n + j] = acc[r][c];
+                    inter[(int64_t)j * n + i] = acc[r][c];
+                }
+            }
+            flag[ti * 4 + r][tj * 4 + c] = ok ? 1 : 0;
+        }
+    __syncthreads();
+    if (tid < kT) {
+        const int i = i0 + tid;
+        if (i < n) {
+            uint64_t w = 0;
+            for (int c = 0; c < kT; ++c) w |= (uint64_t)flag[tid][c] << c;
+            adj[(int64_t)i * aw + bj] = w;
+        }
+    } else if (tid < 2 * kT && bi != bj) {
+        const int c = tid - kT, j = j0 + c;
+        if (j < n) {
+            uint64_t w = 0;
+            for (int r = 0; r < kT; ++r) w |= (uint64_t)flag[r][c] << r;
+            adj[(int64_t)j * aw + bi] = w;
+        }
+    }
+}
+
+// ---- group OR / confidence mean ---------------------------------------------------------------
+__global__ void or_reduce_groups_kernel(const uint64_t *__restrict__ rows, int64_t nw,
+                                        const int32_t *__restrict__ offs, const int32_t *__restrict__ members,
+                                        uint64_t *__restrict__ out)
+{
+    const int g = blockIdx.y;
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    uint64_t v = 0;
+    for (int m = offs[g]; m < offs[g + 1]; ++m) v |= rows[(int64_t)members[m] * nw + w];
+    out[(int64_t)g * nw + w] = v;
+}
+
+template <typename T>
+__global__ void group_conf_mean_kernel(const T *__restrict__ conf, const int32_t *__restrict__ offs,
+                                       const int32_t *__restrict__ members, int n_groups, T *__restrict__ mean)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const int lo = offs[g], hi = offs[g + 1];
+    if constexpr (sizeof(T) == 2) {
+        __half s = __float2half_rn(0.0f);
+        for (int m = lo; m < hi; ++m) s = __hadd(s, conf[members[m]]);    // one f16 rounding per step
+        mean[g] = __float2half_rn(__fdiv_rn(__half2float(s), (float)(hi - lo)));
+    } else {
+        float s = 0.0f;
+        for (int m = lo; m < hi; ++m) s = __fadd_rn(s, conf[members[m]]);
+        mean[g] = __fdiv_rn(s, (float)(hi - lo));
+    }
+}
+
+// ---- row programs -----------------------------------------------------------------------------
+__global__ void apply_row_ops_kernel(uint64_t *__restrict__ rows, int64_t nw, const int32_t *__restrict__ ops,
+                                     int n_ops)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    for (int k = 0; k < n_ops; ++k) {
+        const int op = ops[3 * k], d = ops[3 * k + 1], s = ops[3 * k + 2];
+        const uint64_t sv = rows[(int64_t)s * nw + w];
+        uint64_t *dp = rows + (int64_t)d * nw + w;
+        *dp = op == 0 ? (*dp & ~sv) : op == 1 ? (*dp | sv) : sv;
+    }
+}
+
+__global__ void and_rows_kernel(uint64_t *__restrict__ rows, int64_t nw, const uint64_t *__restrict__ keep)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw) rows[(int64_t)blockIdx.y * nw + w] &= keep[w];
+}
+
+__global__ void gather_rows_kernel(const uint64_t *__restrict__ rows, const int32_t *__restrict__ idx, int64_t nw,
+                                   uint64_t *__restrict__ out)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw) out[(int64_t)blockIdx.y * nw + w] = rows[(int64_t)idx[blockIdx.y] * nw + w];
+}
+
+// ---- dense <-> bits ---------------------------------------------------------------------------
+__global__ void unpack_rows_kernel(const uint64_t *__restrict__ rows, int64_t nw, int64_t n, uint8_t *__restrict__ dense)
+{
+    // one thread expands 8 points (one byte of the bit row) into 8 bytes
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // group of 8 points
+    const int64_t p0 = g * 8;
+    if (p0 >= n) return;
+    const uint32_t byte = (uint32_t)(rows[(int64_t)blockIdx.y * nw + (p0 >> 6)] >> (p0 & 63)) & 0xFFu;
+    // 4 bits -> 4 bytes: the partial products land on disjoint bits, so there are no carries
+    const uint32_t lo = ((byte & 0xF) * 0x00204081u) & 0x01010101u;
+    const uint32_t hi = ((byte >> 4) * 0x00204081u) & 0x01010101u;
+    uint8_t *out = dense + (int64_t)blockIdx.y * n + p0;
+    if (p0 + 8 <= n && (((uintptr_t)out) & 7) == 0) {
+        *reinterpret_cast<uint64_t *>(out) = (uint64_t)lo | ((uint64_t)hi << 32);
+    } else {
+        for (int k = 0; k < 8 && p0 + k < n; ++k) out[k] = (byte >> k) & 1;
+    }
+}
+
+__global__ void pack_rows_kernel(const uint8_t *__restrict__ dense, int64_t n, int64_t nw, uint64_t *__restrict__ rows)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool bit = p < n && dense[(int64_t)blockIdx.y * n + p] != 0;
+    const uint64_t bal = __ballot(bit);
+    if (lane_id() == 0 && (p >> 6) < nw) rows[(int64_t)blockIdx.y * nw + (p >> 6)] = bal;
+}
+
+// ---- 1-D RLE -> bit rows ----------------------------------------------------------------------
+__global__ void rle_to_rows_kernel(const int32_t *__restrict__ run_start, const int32_t *__restrict__ run_end,
+                                   const int32_t *__restrict__ offs, int64_t n, int64_t nw, uint64_t *__restrict__ rows)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    const int g = blockIdx.y;
+    const int64_t p0 = w * 64, p1 = p0 + 64;
+    int lo = offs[g], hi = offs[g + 1], r = hi;
+    while (lo < r) {                                  // first run with end > p0
+        const int mid = (lo + r) >> 1;
+        if ((int64_t)run_end[mid] > p0) r = mid; else lo = mid + 1;
+    }
+    uint64_t v = 0;
+    for (; r < hi; ++r) {
+        const int64_t s = run_start[r], e = run_end[r];
+        if (s >= p1) break;
+        const int a = (int)(max(s, p0) - p0), b = (int)(min(e, p1) - p0);    // [a, b) within the word, b > a
+        const uint64_t upto_b = b >= 64 ? ~0ull : ((1ull << b) - 1);
+        v |= upto_b & ~((1ull << a) - 1);
+    }
+    if (p1 > n) v &= (n - p0 >= 64) ? ~0ull : ((1ull << (n - p0)) - 1);
+    rows[(int64_t)g * nw + w] = v;
+}
+
+}  // namespace bff
+
+using namespace bff;
+
+extern "C" int bff_popcount_rows(const uint64_t *rows, const int32_t *idx, int32_t n_rows, int64_t nw,
+                                 int32_t *area, void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_popcount_rows: bad sizes");
+    if (n_rows == 0) return BFF_OK;
+    BFF_REQUIRE(rows && area, "bff_popcount_rows: null pointer");
+    popcount_rows_kernel<<<n_rows, 256, 0, as_stream(stream)>>>(rows, idx, nw, area);
+    return launched("bff_popcount_rows");
+}
+
+extern "C" int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t na, const uint64_t *b,
+                                  const int32_t *ib, int32_t nb, int64_t nw, int32_t *inter, void *stream)
+{
+    BFF_REQUIRE(na >= 0 && nb >= 0 && nw >= 0, "bff_cross_popcount: bad sizes");
+    if (na == 0 || nb == 0) return BFF_OK;
+    BFF_REQUIRE(a && b && inter, "bff_cross_popcount: null pointer");
+    dim3 grid((unsigned)ceil_div(nb, kT), (unsigned)ceil_div(na, kT));
+    cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, ia, na, b, ib, nb, nw, inter);
+    return launched("bff_cross_popcount");
+}
+
+extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *area,
+                                   const int32_t *label_id, float iou_thres, uint64_t *adj, int32_t *inter,
+                                   void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_merge_adjacency: bad sizes");
+    if (n_rows == 0) return BFF_OK;
+    BFF_REQUIRE(rows && area && label_id && adj, "bff_merge_adjacency: null pointer");
+    const int nt = (int)ceil_div(n_rows, kT);
+    BFF_LIMIT((int64_t)nt * (nt + 1) / 2 < (1ll << 31), "bff_merge_adjacency: too many rows");
+    const int aw = nt;   // ceil(n_rows/64) words per adjacency row
+    merge_adjacency_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, as_stream(stream)>>>(
+        rows, n_rows, nw, area, label_id, iou_thres, adj, aw, inter, nt);
+    return launched("bff_merge_adjacency");
+}
+
+extern "C" int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int32_t *group_offs,
+                                    const int32_t *members, int32_t n_groups, uint64_t *out, void *stream)
+{
+    BFF_REQUIRE(n_groups >= 0 && nw >= 0, "bff_or_reduce_groups: bad sizes");
+    if (n_groups == 0 || nw == 0) return BFF_OK;
+    BFF_REQUIRE(rows && group_offs && members && out, "bff_or_reduce_groups: null pointer");
+    dim3 grid((unsigned)ceil_div(nw, 256), (unsigned)n_groups);
+    or_reduce_groups_kernel<<<grid, 256, 0, as_stream(stream)>>>(rows, nw, group_offs, members, out);
+    return launched("bff_or_reduce_groups");
+}
+
+extern "C" int bff_group_conf_mean(const void *conf, int32_t dtype, const int32_t *group_offs,
+                                   const int32_t *members, int32_t n_groups, void *mean, void *stream)
+{
+    BFF_REQUIRE(n_groups >= 0 && (dtype == 0 || dtype == 1), "bff_group_conf_mean: bad arguments");
+    if (n_groups == 0) return BFF_OK;
+    BFF_REQUIRE(conf && group_offs && members && mean, "bff_group_conf_mean: null pointer");
+    const unsigned grid = (unsigned)ceil_div(n_groups, 64);
+    if (dtype == 1)
+        group_conf_mean_kernel<__half><<<grid, 64, 0, as_stream(stream)>>>((const __half *)conf, group_offs, members,
+                                                                           n_groups, (__half *)mean);
+    else
+        group_conf_mean_kernel<float><<<grid, 64, 0, as_stream(stream)>>>((const float *)conf, group_offs, members,
+                                                                          n_groups, (float *)mean);
+    return launched("bff_group_conf_mean");
+}
+
+extern "C" int bff_apply_row_ops(uint64_t *rows, int64_t nw, const int32_t *ops, int32_t n_ops, void *stream)
+{
+    BFF_REQUIRE(n_ops >= 0 && nw >= 0, "bff_apply_row_ops: bad sizes");
+    if (n_ops == 0 || nw == 0) return BFF_OK;
+    BFF_REQUIRE(rows && ops, "bff_apply_row_ops: null pointer");
+    apply_row_ops_kernel<<<(unsigned)ceil_div(nw, 256), 256, 0, as_stream(stream)>>>(rows, nw, ops, n_ops);
+    return launched("bff_apply_row_ops");
+}
+
+extern "C" int bff_and_rows(uint64_t *rows, int32_t n_rows, int64_t nw, const uint64_t *keep, void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_and_rows: bad sizes");
+    if (n_rows == 0 || nw == 0) return BFF_OK;
+    BFF_REQUIRE(rows && keep, "bff_and_rows: null pointer");
+    dim3 grid((unsigned)ceil_div(nw, 256), (unsigned)n_rows);
+    and_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(rows, nw, keep);
+    return launched("bff_and_rows");
+}
+
+extern "C" int bff_gather_rows(const uint64_t *rows, const int32_t *idx, int32_t n_out, int64_t nw, uint64_t *out,
+                               void *stream)
+{
+    BFF_REQUIRE(n_out >= 0 && nw >= 0, "bff_gather_rows: bad sizes");
+    if (n_out == 0 || nw == 0) return BFF_OK;
+    BFF_REQUIRE(rows && idx && out, "bff_gather_rows: null pointer");
+    dim3 grid((unsigned)ceil_div(nw, 256), (unsigned)n_out);
+    gather_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(rows, idx, nw, out);
+    return launched("bff_gather_rows");
+}
+
+extern "C" int bff_unpack_rows(const uint64_t *rows, int32_t n_rows, int64_t nw, int64_t n_points, uint8_t *dense,
+                               void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && n_points >= 0 && nw == ceil_div(n_points, 64), "bff_unpack_rows: bad sizes");
+    if (n_rows == 0 || n_points == 0) return BFF_OK;
+    BFF_REQUIRE(rows && dense, "bff_unpack_rows: null pointer");
+    dim3 grid((unsigned)ceil_div(ceil_div(n_points, 8), 256), (unsigned)n_rows);
+    unpack_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(rows, nw, n_points, dense);
+    return launched("bff_unpack_rows");
+}
+
+extern "C" int bff_pack_rows(const uint8_t *dense, int32_t n_rows, int64_t n_points, int64_t nw, uint64_t *rows,
+                             void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && n_points >= 0 && nw == ceil_div(n_points, 64), "bff_pack_rows: bad sizes");
+    if (n_rows == 0 || n_points == 0) return BFF_OK;
+    BFF_REQUIRE(rows && dense, "bff_pack_rows: null pointer");
+    dim3 grid((unsigned)ceil_div(nw * 64, 256), (unsigned)n_rows);
+    pack_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(dense, n_points, nw, rows);
+    return launched("bff_pack_rows");
+}
+
+extern "C" int bff_rle_to_rows(const int32_t *run_start, const int32_t *run_end, const int32_t *row_run_offs,
+                               int32_t n_rows, int64_t n_points, int64_t nw, uint64_t *rows, void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && n_points >= 0 && nw == ceil_div(n_points, 64), "bff_rle_to_rows: bad sizes");
+    if (n_rows == 0 || nw == 0) return BFF_OK;
+    BFF_REQUIRE(row_run_offs && rows, "bff_rle_to_rows: null pointer");   // run arrays may be empty (NULL)
+    dim3 grid((unsigned)ceil_div(nw, 256), (unsigned)n_rows);
+    rle_to_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(run_start, run_end, row_run_offs, n_points, nw, rows);
+    return launched("bff_rle_to_rows");
+}

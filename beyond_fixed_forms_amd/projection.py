@@ -1,0 +1,199 @@
+"""Stage 2 of the pipeline on MI355X: 2-D masks -> aggregated, filtered 3-D instance masks.
+
+Host-side mirror of the per-scene loop of the reference (tools/projection_2d_to_3d.py:365-634).
+All per-point / per-pixel / per-pair arithmetic runs in libbff_hip.so (include/bff_hip.h); the host
+keeps only what the reference keeps sequential and tiny: grouping component labels into the
+reference's list order, the order-dependent overlap decisions (P:295-299), thresholds picked from
+sets of distinct values, and dict assembly.  `P:` = tools/projection_2d_to_3d.py.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import List
+
+import numpy as np
+import torch
+
+from . import _lib
+from .scene import DEPTH_THRESH, DeviceScene, prepare_scene
+
+
+@dataclasses.dataclass
+class Stage2Result:
+    """Output of the projection stage, kept bit-packed on the device.
+
+    `to_dict()` gives exactly what the reference saves at P:630-634:
+    {"ins": bool (K,N) device tensor, "conf": (K,) tensor, "final_class": list[str]} or, when
+    nothing survives, the reference's empty form (P:468-470, 499-501)."""
+    scene_id: str
+    n_points: int
+    rows: torch.Tensor            # int64 [K][nw] bit rows (device)
+    conf: torch.Tensor            # (K,) in the dtype of the input confidences (device)
+    final_class: List[str]
+    groups: list                  # indices of the raw 2-D masks merged into each *pre-filter* instance
+    debug: dict
+
+    @property
+    def empty(self):
+        return self.rows.shape[0] == 0 and self.debug.get("empty_form", False)
+
+    def to_dict(self):
+        if self.debug.get("empty_form", False):
+            dev = self.rows.device
+            return {"ins": torch.tensor([[]]).to(dev), "conf": torch.tensor([]).to(dev), "final_class": []}
+        return {"ins": _lib.unpack_rows(self.rows, self.n_points), "conf": self.conf,
+                "final_class": list(self.final_class)}
+
+
+def _empty(ds: DeviceScene, debug) -> Stage2Result:
+    debug["empty_form"] = True
+    return Stage2Result(ds.scene_id, ds.n_points, torch.zeros((0, ds.nw), dtype=torch.int64, device=ds.xyz.device),
+                        torch.zeros(0, device=ds.xyz.device), [], [], debug)
+
+
+def groups_from_labels(label: np.ndarray, has_self_loop: np.ndarray):
+    """Component labels (smallest member index) -> the list find_unconnected_subgraphs_tensor
+    returns (P:262-274): components in order of their smallest index, members ascending; a node
+    whose adjacency row is empty (no self loop: empty mask, IoU NaN) yields an empty list."""
+    n = label.shape[0]
+    order = np.argsort(label, kind="stable")           # members of a component, ascending, grouped by root
+    sl = has_self_loop[order]
+    lab_sorted = label[order]
+    comps = {}
+    if n:
+        cut = np.flatnonzero(np.diff(lab_sorted)) + 1
+        for seg in np.split(np.arange(n), cut):
+            root = int(lab_sorted[seg[0]])
+            members = order[seg][sl[seg]]
+            if members.size:
+                comps[root] = members.tolist()
+    out = []
+    for i in range(n):
+        if not has_self_loop[i]:
+            out.append([])
+        elif i in comps:
+            out.append(comps[i])
+    return out
+
+
+def _threshold_from_lattice(presence: np.ndarray, v_max: int, fraction: float, ratio: bool) -> np.float32:
+    """unique()[floor(fraction * n_unique)] over the distinct values of masked/(viewed+1) (P:571-576)
+    or of masked (P:513-518), from the set of occurring (masked, viewed) pairs."""
+    cells = np.flatnonzero(presence)
+    m = (cells // (v_max + 1)).astype(np.float32)
+    if ratio:
+        v = (cells % (v_max + 1)).astype(np.float32)
+        vals = m / (v + np.float32(1.0))                 # float32 IEEE division, like torch
+    else:
+        vals = m
+    uniq = np.unique(vals)
+    return uniq[math.floor(fraction * uniq.shape[0])]
+
+
+def run_projection(ds: DeviceScene, cfg, debug_out: bool = False) -> Stage2Result:
+    """P:402-634 for one uploaded scene."""
+    dev = ds.xyz.device
+    dbg = {}
+    n, nw = ds.n_points, ds.nw
+    do_ratio = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
+
+    # a1: RLE -> per-pixel mask words (never the dense (M,1,H,W) tensors of P:400)
+    n_mviews = ds.view_mask_offs.shape[0] - 1
+    maskbits = torch.empty((n_mviews, ds.height * ds.width), device=dev,
+                           dtype=torch.int32 if ds.word_bits == 32 else torch.int64)
+    _lib.rle_to_maskbits(ds.run_start, ds.run_end, ds.mask_run_offs, ds.view_mask_offs, n_mviews,
+                         ds.height * ds.width, ds.word_bits, maskbits)
+
+    # a2-a8 (+a15): one fused sweep over the frames (P:413-461 and P:538-567)
+    rows = torch.empty((ds.n_rows, nw), dtype=torch.int64, device=dev)
+    masked = torch.zeros(n, dtype=torch.int32, device=dev)                          # P:402
+    viewed = torch.zeros(n, dtype=torch.int32, device=dev) if do_ratio else None    # P:537
+    n_frames = ds.n_frames if do_ratio else ds.n_mask_frames
+    _lib.project_views(ds.xyz, n, ds.inv_pose[:n_frames], ds.cam_intr, ds.depth, ds.depth_index, ds.height,
+                       ds.width, DEPTH_THRESH, maskbits if n_mviews else None, ds.word_bits, ds.frame_mask,
+                       ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows if ds.n_rows else None,
+                       masked, viewed)
+    del maskbits
+    if debug_out:
+        dbg["raw_rows"], dbg["masked_counts_raw"] = rows, masked.clone()
+    if ds.n_rows == 0:                                                              # P:465-478
+        return _empty(ds, dbg)
+
+    # a9-a12: IoU / label adjacency and its connected components (P:100-146, 250-274)
+    area = _lib.popcount_rows(rows)
+    adj = _lib.merge_adjacency(rows, area, ds.label_id, cfg.iou_thres)
+    label = _lib.components(adj).cpu().numpy()
+    area_h = area.cpu().numpy()
+    self_loop = (area_h > 0) & bool(np.float32(1.0) > np.float32(cfg.iou_thres))
+    comps = groups_from_labels(label, self_loop)
+    groups = [g for g in comps if len(g) >= cfg.min_aggragated_masks]               # P:203
+    dbg["groups"] = groups
+    merged = [g for g in groups if g != []]                                         # P:216-217
+    if not merged:                                                                  # P:230-236, 496-509
+        return _empty(ds, dbg)
+
+    # a13: OR of member rows, sequential mean of confidences, label of the first member (P:214-226)
+    offs = np.zeros(len(merged) + 1, dtype=np.int32)
+    np.cumsum([len(g) for g in merged], out=offs[1:])
+    members = np.concatenate([np.asarray(g, dtype=np.int32) for g in merged])
+    offs_d, members_d = torch.from_numpy(offs).to(dev), torch.from_numpy(members).to(dev)
+    agg = _lib.or_reduce_groups(rows, offs_d, members_d)
+    conf = _lib.group_conf_mean(ds.conf, offs_d, members_d)
+    agg_labels = [ds.labels[g[0]] for g in merged]
+    if not debug_out:
+        del rows
+
+    # a14/a15: point filter (P:512-583)
+    if cfg.if_occurance_threshold:
+        m_max = int(masked.max().item())
+        pres = _lib.count_lattice(masked, None, m_max, 0).cpu().numpy()
+        thr = _threshold_from_lattice(pres, 0, cfg.occurance_threshold, ratio=False)
+        keep = _lib.ratio_keep(masked, None, thr, True)
+        dbg["thr"] = float(thr)
+    elif do_ratio:
+        m_max = int(masked.max().item())
+        pres = _lib.count_lattice(masked, viewed, m_max, ds.n_viewed).cpu().numpy()
+        thr = _threshold_from_lattice(pres, ds.n_viewed, cfg.detected_ratio_threshold, ratio=True)
+        keep = _lib.ratio_keep(masked, viewed, thr, True)
+        dbg["thr"] = float(thr)
+        if debug_out:
+            dbg["viewed_counts"] = viewed
+    else:
+        keep = _lib.ratio_keep(masked, None, 0.0, False)
+
+    # a16: overlap resolution (P:592-596).  `groups` (not `merged`) indexes the sizes, as in the
+    # reference where num_masks comes from mask_indeces_to_be_merged (P:285) -- identical unless
+    # min_aggragated_masks == 0.
+    before = _lib.popcount_rows(agg)                                                # P:592
+    k = agg.shape[0]
+    inter = _lib.cross_popcount(agg, agg).cpu().numpy()
+    size = [len(g) for g in groups]
+    ops = []
+    for i in range(k):
+        for j in range(i + 1, k):
+            if inter[i, j] > 0:                                                     # P:291 (state before any edit)
+                ops.append((0, j, i) if size[i] > size[j] else (0, i, j))           # P:296-299
+    if ops:
+        _lib.apply_row_ops(agg, torch.tensor(ops, dtype=torch.int32).to(dev))
+    _lib.and_rows(agg, keep)                                                        # P:595
+    after = _lib.popcount_rows(agg)                                                 # P:596
+
+    # a17: size filters with the reference's dtype promotion (int64 vs python scalars, P:601-606)
+    before_t, after_t = before.cpu().to(torch.int64), after.cpu().to(torch.int64)
+    keep_rows = (after_t > cfg.remove_small_masks) & (after_t > cfg.remove_filtered_masks * before_t)
+    idx = torch.nonzero(keep_rows).view(-1).to(torch.int32)
+    dbg.update(before=before_t, after=after_t, keep=keep_rows)
+    out_rows = _lib.gather_rows(agg, idx.to(dev)) if idx.numel() else agg[:0]
+    out_conf = conf[keep_rows.to(dev)]
+    out_labels = [c for c, kk in zip(agg_labels, keep_rows.tolist()) if kk]
+    return Stage2Result(ds.scene_id, n, out_rows, out_conf, out_labels, groups, dbg)
+
+
+def project_scene(scene, cfg, device="cuda", return_result: bool = False, debug_out: bool = False):
+    """Reference-shaped entry point: in-memory scene inputs -> the dict saved at P:630-634."""
+    _lib.load()                                     # fail loudly before any work if the library is missing
+    ds = prepare_scene(scene, cfg, device=device,
+                       with_viewed=(not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold))
+    res = run_projection(ds, cfg, debug_out=debug_out)
+    return res if return_result else res.to_dict()

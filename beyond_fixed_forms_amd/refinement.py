@@ -1,0 +1,256 @@
+"""Stage 3 on MI355X: refine Open3DIS stage-1 masks with the stage-2 masks of one query class.
+
+Host-side mirror of the reference's two-pass ``__main__`` block (tools/refinement.py:135-428,
+`R:` below).  Bit rows stay on the device; the {0,1} matmuls (R:84) are popcount kernels, stage-1
+RLE is decoded on the device (R:26-39), text similarities come from one MFMA cosine GEMM against an
+embedding bank instead of two CLIP encoder calls per matched mask (R:93-115).  The short, order
+dependent bookkeeping (R:230-281) stays on the host, as in the reference.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .labels import SCANNET200_LABELS, idx_to_label
+from .projection import Stage2Result
+from .scene import runs_from_rles
+
+
+# --------------------------------------------------------------------------- text similarity
+class TextSimilarity:
+    """cos(query, label) for every label the class loop can meet, computed once per query with
+    bff_cosine_gemm_f16 (replaces compute_clip_similarity R:93-115, called per matched mask).
+
+    `encode_text(str) -> (1, D) tensor` is the CLIP text encoder (or any stand-in); embeddings are
+    cast to float16 for the matrix cores, accumulation and normalisation are float32."""
+
+    def __init__(self, encode_text: Callable[[str], torch.Tensor], device="cuda", labels: Sequence[str] = SCANNET200_LABELS):
+        self.device = torch.device(device)
+        self.labels = list(labels)
+        with torch.no_grad():
+            bank = torch.cat([encode_text(lab).reshape(1, -1) for lab in self.labels]).to(torch.float16)
+        self.bank = self._pad(bank).to(self.device).contiguous()
+        self.encode_text = encode_text
+        self.index = {lab: i for i, lab in enumerate(self.labels)}
+        self._cache: Dict[str, np.ndarray] = {}
+
+    @staticmethod
+    def _pad(x):
+        d = x.shape[1]
+        pad = (-d) % 32
+        return torch.nn.functional.pad(x, (0, pad)) if pad else x
+
+    def query(self, text: str) -> np.ndarray:
+        """float32 [n_labels]: cosine of `text` against every bank label."""
+        if text not in self._cache:
+            with torch.no_grad():
+                q = self._pad(self.encode_text(text).reshape(1, -1).to(torch.float16)).to(self.device).contiguous()
+            self._cache[text] = _lib.cosine_gemm_f16(q, self.bank)[0].cpu().numpy()
+        return self._cache[text]
+
+    def similarities(self, text: str, labels: Sequence[str]) -> List[float]:
+        row = self.query(text)
+        return [float(row[self.index[lab]]) for lab in labels]
+
+
+# --------------------------------------------------------------------------- inputs
+def _stage2_rows(stage2, n_points, device):
+    """Stage-2 result (Stage2Result or the reference's dict) -> (bit rows [K][nw], conf (K,) on CPU)."""
+    if isinstance(stage2, Stage2Result):
+        return stage2.rows, stage2.conf.cpu()
+    conf = stage2["conf"]
+    if len(conf) == 0:                                                              # R:196
+        return torch.zeros((0, (n_points + 63) // 64), dtype=torch.int64, device=device), torch.as_tensor(conf).cpu()
+    ins = stage2["ins"].to(device)
+    if ins.dtype not in (torch.bool, torch.uint8):
+        ins = ins != 0
+    return _lib.pack_rows(ins.contiguous()), conf.cpu()
+
+
+def _stage1_rows(stage1, device):
+    """Open3DIS stage-1 dict -> (bit rows [S1][nw], n_points, label strings).  R:186-193."""
+    rles = stage1["ins"]
+    n_points = int(rles[0]["length"])
+    if any(int(r["length"]) != n_points for r in rles):
+        raise ValueError("stage-1 masks of different lengths")
+    rs, re, offs = runs_from_rles(rles, "stage-1")
+    t = lambda a: torch.from_numpy(a).to(device)
+    rows = _lib.rle_to_rows(t(rs), t(re), t(offs), n_points)
+    return rows, n_points, [idx_to_label(int(i)) for i in stage1["final_class"]]
+
+
+def _iou(inter: torch.Tensor, area_a: torch.Tensor, area_b: torch.Tensor) -> torch.Tensor:
+    """calculate_iou_between_stages R:69-90 from integer intersections: (m, n) float32."""
+    inter = inter.to(torch.float32)
+    union = area_a.to(torch.float32).unsqueeze(1) + area_b.to(torch.float32).unsqueeze(0) - inter
+    return (inter / union).T
+
+
+@dataclasses.dataclass
+class _SceneState:
+    scene_id: str
+    n_points: int
+    ious: object                 # tensor (m,) or []
+    sims: list
+    matched1: Optional[torch.Tensor]   # bit rows (m, nw)
+    stage2_rows: Optional[torch.Tensor]
+    stage2_conf: object
+    other1: torch.Tensor         # bit rows (o, nw)
+
+
+def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: TextSimilarity, device) -> _SceneState:
+    s1, n, s1_labels = _stage1_rows(stage1, device)
+    s2, conf2 = _stage2_rows(stage2, n, device)
+    i32 = lambda lst: torch.tensor(lst, dtype=torch.int32, device=device)
+    if len(conf2) == 0:                                                             # R:196-205
+        other = [i for i, lab in enumerate(s1_labels) if lab == query_us]
+        return _SceneState(scene_id, n, [], [], None, None, [], _lib.gather_rows(s1, i32(other)) if other else s1[:0])
+
+    area1 = _lib.popcount_rows(s1).cpu()
+    area2 = _lib.popcount_rows(s2).cpu()
+    iou = _iou(_lib.cross_popcount(s1, s2).cpu(), area1, area2)                     # R:208  (K, S1)
+    best = torch.argmax(iou, dim=1)                                                 # R:211
+    b32 = best.to(torch.int32).to(device)
+    m_iou = _iou(_lib.cross_popcount(s1, s1, b32, b32).cpu(), area1[best], area1[best])   # R:217
+    k = len(best)
+    m_iou[range(k), range(k)] = 0                                                   # R:221
+    m_adj = (m_iou > cfg.stage1_iou_thres).to(int)                                  # R:224
+
+    chosen, ops = [], []                                                            # R:230-249
+    absorbed_by = [-1] * k
+    for i in range(k):
+        if absorbed_by[i] != -1:
+            chosen.append(int(best[absorbed_by[i]]))
+            continue
+        chosen.append(int(best[i]))
+        if m_adj[i].sum() > 0:
+            for j in range(k):
+                if m_adj[i][j] == 1:
+                    absorbed_by[j] = i
+                    ops.append((1, int(best[i]), int(best[j])))                     # R:248 in-place OR
+    if ops:
+        _lib.apply_row_ops(s1, torch.tensor(ops, dtype=torch.int32).to(device))
+
+    # R:258-281: stage-2 masks matched to the same stage-1 mask are merged; each current row is
+    # tracked as the list of original stage-2 rows it is the OR of
+    chosen_t = torch.tensor(chosen)
+    parts = [[i] for i in range(k)]
+    uniq, cnt = torch.unique(chosen_t, return_counts=True)
+    for u, c in zip(uniq, cnt):
+        if c > 1:
+            sel = chosen_t == u
+            mconf = conf2[sel].mean()
+            merged = [p for keep, part in zip(sel.tolist(), parts) if keep for p in part]
+            parts = [part for keep, part in zip(sel.tolist(), parts) if not keep] + [merged]
+            conf2 = torch.cat([conf2[~sel], mconf.unsqueeze(0)])
+            chosen_t = torch.cat([chosen_t[~sel], u.unsqueeze(0)])
+    if any(len(p) > 1 for p in parts) or len(parts) != k:
+        offs = np.zeros(len(parts) + 1, dtype=np.int32)
+        np.cumsum([len(p) for p in parts], out=offs[1:])
+        s2 = _lib.or_reduce_groups(s2, torch.from_numpy(offs).to(device),
+                                   i32([p for part in parts for p in part]))
+
+    area1 = _lib.popcount_rows(s1).cpu()                                            # stage-1 rows may have grown
+    area2 = _lib.popcount_rows(s2).cpu()
+    iou = _iou(_lib.cross_popcount(s1, s2).cpu(), area1, area2)                     # R:285
+    best = torch.argmax(iou, dim=1)                                                 # R:288
+    best_l = best.tolist()
+    other = [i for i, lab in enumerate(s1_labels) if lab == query_us and i not in best_l]   # R:293
+    labels = [s1_labels[i] for i in best_l]                                         # R:297
+    sims = sim.similarities(text_prompt, labels)                                    # R:299-302
+    return _SceneState(scene_id, n, iou[range(len(best)), best], sims,
+                       _lib.gather_rows(s1, best.to(torch.int32).to(device)), s2, conf2,
+                       _lib.gather_rows(s1, i32(other)) if other else s1[:0])
+
+
+@dataclasses.dataclass
+class FinalResult:
+    """Final output of one scene, bit-packed on the device; to_dict() = what R:354-357 / R:405-408 /
+    R:423-426 save (including the reference's list-valued empty forms)."""
+    scene_id: str
+    n_points: int
+    rows: Optional[torch.Tensor]      # int64 [R][nw] or None when the reference saves python lists
+    conf: object
+    final_class: List[str]
+
+    def to_dict(self):
+        if self.rows is None:
+            return {"ins": [], "conf": [], "final_class": list(self.final_class)}
+        return {"ins": _lib.unpack_rows(self.rows, self.n_points), "conf": self.conf,
+                "final_class": list(self.final_class)}
+
+
+def sim_threshold(all_sims: Sequence[Sequence[float]], percentile: float) -> float:
+    """R:321-324: sorted(set(all similarities of all scenes))[int(n * percentile)]."""
+    uniq = sorted(set(s for sims in all_sims for s in sims))
+    return uniq[int(len(uniq) * percentile)]
+
+
+def _pass2_scene(st: _SceneState, cfg, text_prompt, sim_thres) -> FinalResult:
+    """R:330-428 for one scene."""
+    dev = st.other1.device
+    pieces, conf, cls = [], [], []
+    n_other = st.other1.shape[0]
+    if n_other:                                                                     # R:340-343
+        pieces.append(st.other1)
+        conf += [torch.tensor(0.5)] * n_other
+        cls += [text_prompt] * n_other
+    if len(st.ious) == 0:                                                           # R:348-358
+        if n_other == 0:
+            return FinalResult(st.scene_id, st.n_points, None, [], [])
+        return FinalResult(st.scene_id, st.n_points, st.other1, torch.stack(conf), cls)
+    take1, take2 = [], []
+    order = []                                  # (source, index) in output order
+    for m, v in enumerate(st.ious):                                                 # R:360-392
+        if v > cfg.refiment_iou_thres:
+            if st.sims[m] < sim_thres:
+                continue
+            order.append((1, m))
+        else:
+            order.append((2, m))
+        conf.append(st.stage2_conf[m])
+        cls.append(text_prompt)
+    if n_other == 0 and not order:                                                  # R:402-409
+        return FinalResult(st.scene_id, st.n_points, None, [], [])
+    if order:
+        both = torch.cat([st.matched1, st.stage2_rows])
+        k = st.matched1.shape[0]
+        idx = torch.tensor([m if src == 1 else k + m for src, m in order], dtype=torch.int32, device=dev)
+        pieces.append(_lib.gather_rows(both, idx))
+    rows = torch.cat(pieces) if len(pieces) > 1 else pieces[0]
+    return FinalResult(st.scene_id, st.n_points, rows, torch.stack(conf), cls)       # R:411-412
+
+
+def refine_class(scenes, cfg, text_prompt: str, sim: TextSimilarity, device="cuda",
+                 exchange_sims: Optional[Callable[[List[List[float]]], List[List[float]]]] = None,
+                 return_debug: bool = False):
+    """Reference R:135-428 on in-memory inputs.
+
+    scenes: list of (scene_id, stage1_dict_or_None, stage2) in the sorted order of the stage-2
+    directory listing (R:154); stage2 is a Stage2Result, the reference's saved dict, or None for a
+    missing file (R:175-178: such scenes are skipped in pass 1).  `exchange_sims` lets the
+    multi-GPU driver widen the similarity set of pass 1 to all ranks (the one cross-scene
+    dependency of the path, R:316-324).  Returns {scene_id: FinalResult}."""
+    _lib.load()
+    query_us = text_prompt.replace(" ", "_")                                        # R:142
+    states = []
+    for scene_id, stage1, stage2 in scenes:                                         # R:166
+        if stage1 is None or stage2 is None:
+            continue
+        states.append(_pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim, device))
+    all_sims = [st.sims for st in states]
+    pool = exchange_sims(all_sims) if exchange_sims is not None else all_sims
+    thres = sim_threshold(pool, cfg.refinment_sim_percentile)                       # R:321-324
+    out = {}
+    for s, (scene_id, _s1, _s2) in enumerate(scenes):                               # R:330 (index s, as the reference)
+        st = states[s]
+        res = _pass2_scene(st, cfg, text_prompt, thres)
+        res.scene_id = scene_id
+        out[scene_id] = res
+    if return_debug:
+        return out, {"sim_thres": thres, "states": states}
+    return out

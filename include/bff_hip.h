@@ -1,0 +1,192 @@
+/* bff_hip.h -- C ABI of libbff_hip.so: the MI355X (gfx950) kernels behind the 2D->3D mask
+ * projection + multi-view fusion + refinement hot path of Beyond-Fixed-Forms.
+ *
+ * The reference has no FFI/operator ABI for this path: its boundary is files + Python dicts
+ * (SURVEY.md section 8b).  This header is therefore the seam between this repo's Python host
+ * (the beyond_fixed_forms_amd Python modules, which mirror the reference's dict/CLI interface) and its HIP
+ * kernels.  Each entry point cites the reference lines whose arithmetic it replaces; paths are
+ * relative to the reference checkout (tools/projection_2d_to_3d.py = P, tools/refinement.py = R,
+ * tools/utils/rle_encode_decode.py = RLE, tools/segmentation_2d.py = SEG).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory
+ *     (the host allocates through torch); no entry point allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - return value: 0 = launched, <0 = rejected argument (BFF_E_*), >0 = hipError_t of the launch;
+ *     bff_last_error() gives a message for the calling thread;
+ *   - "bit rows": a boolean row over N points is stored as ceil(N/64) uint64 words, point n is bit
+ *     (n & 63) of word (n >> 6); padding bits of the last word are always 0;  `nw` = ceil(N/64);
+ *   - integers are exact, float64 geometry is bit-exact w.r.t. the reference (see bff_project_views).
+ */
+#ifndef BFF_HIP_H
+#define BFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFF_OK 0
+#define BFF_E_ARG (-1)      /* null pointer / negative size / unsupported parameter */
+#define BFF_E_LIMIT (-2)    /* size beyond what a kernel supports (documented per call) */
+
+#define BFF_ABI_VERSION 1
+
+int bff_abi_version(void);
+const char *bff_last_error(void);
+/* gfx target the library was compiled for ("gfx950"). */
+const char *bff_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * a1 -- 2-D RLE masks -> per-pixel mask words.   Replaces RLE.rle_decode_batch (RLE:35-61) +
+ * decode_2d_masks (RLE:82-99) + the float conversion at P:417-421; the dense (M,1,H,W) uint8
+ * tensors (11.3 GB per scene at 200k x 300 x 30) are never materialised.
+ *
+ * Mask-view v owns masks [view_mask_offs[v], view_mask_offs[v+1]) (at most `word_bits` of them);
+ * mask g owns runs [mask_run_offs[g], mask_run_offs[g+1]); run r covers flattened row-major pixels
+ * [run_start[r], run_end[r]) (0-based, end exclusive, clipped to H*W by the host).  Runs of one
+ * mask must be sorted and disjoint (what rle_encode_batch RLE:10-32 emits; the host normalises
+ * anything else).  Output: maskbits[v][p] has bit b set iff pixel p lies in mask view_mask_offs[v]+b.
+ * word_bits = 32 -> uint32 words, 64 -> uint64 words.
+ */
+int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const int32_t *mask_run_offs,
+                        const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels, int32_t word_bits,
+                        void *maskbits, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a2-a7 (+a15) -- fused per-frame: world->camera transform, projection, rounding, bounds +
+ * depth test, mask-word gather, instance bit rows and the two per-point vote counters.
+ * Replaces, per frame: P:424-425 (inv(pose) @ cloud), compute_projected_pts_tensor P:37-48,
+ * compute_visibility_mask_tensor P:51-70 (depth_thresh is passed by the caller: 0.08 at P:438,565),
+ * compute_visible_masked_pts_tensor P:73-92, the scatter-adds P:459-461 and, for the
+ * detection-ratio sweep, P:548-567.
+ *
+ *   xyz          float64 [3][n_pad] structure-of-arrays (x row, y row, z row), n_pad >= n_points
+ *   inv_pose     float64 [n_frames][16] row-major inverse camera pose (np.linalg.inv on the host)
+ *   cam_intr     float64 [9] row-major K (HOST pointer; copied into kernel arguments)
+ *   depth        float32 [n_depth][H*W] metres; frame f uses image depth_index[f]
+ *   frame_mask   int32 [n_frames]: index of the frame's mask-word image in `maskbits`, or -1
+ *   frame_rowbase int32 [n_frames]: first instance row of the frame (row = rowbase + bit)
+ *   frame_nmask  int32 [n_frames]: number of masks (bits) of the frame, 0..word_bits
+ *   frame_flags  int32 [n_frames]: bit0 = add visibility to viewed_count (P:567)
+ *   rows         uint64 [n_rows][nw] instance bit rows, written (not accumulated) for every frame
+ *                with a mask image: row (rowbase+b), all nw words                        (a6, a8)
+ *   masked_count int32 [n_points], += number of masks of the frame containing the visible point
+ *                (P:459-461 adds 1 per mask, not per view); may be NULL
+ *   viewed_count int32 [n_points], += visibility for frames with flag bit0; may be NULL
+ *
+ * Arithmetic contract (bit-exact with NumPy/OpenBLAS float64 as used by the reference):
+ *   c_i = fma chain over k = 0..3 of inv_pose[i][k] * (x, y, z, 1)[k] starting from +0.0;
+ *   p_i = fma chain over k = 0..2 of K[i][k] * c[k];  u = rint(p_0 / c_2), v = rint(p_1 / c_2)
+ *   (IEEE division, round half to even); in bounds iff 0 <= u < W and 0 <= v < H evaluated on the
+ *   doubles (NaN/inf/out-of-int64-range fail, which equals the reference's INT64_MIN cast);
+ *   visible iff depth != 0 and fabs(c_2 - (double)depth) < depth_thresh.  No z > 0 test.
+ */
+int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
+                      const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
+                      const float *depth, const int32_t *depth_index, int32_t height, int32_t width,
+                      double depth_thresh,
+                      const void *maskbits, int32_t word_bits,
+                      const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
+                      const int32_t *frame_flags,
+                      uint64_t *rows, int64_t n_rows, int64_t nw,
+                      int32_t *masked_count, int32_t *viewed_count, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bit-row primitives (a8-a13, a16-a20).
+ */
+
+/* area[r] = popcount(rows[idx ? idx[r] : r])          (torch.sum(dim=1) at P:161,592,596; R:86-87) */
+int bff_popcount_rows(const uint64_t *rows, const int32_t *idx, int32_t n_rows, int64_t nw,
+                      int32_t *area, void *stream);
+
+/* inter[i][j] = popcount(a[ia[i]] & b[ib[j]]), int32 [na][nb]: the {0,1} matmuls of
+ * calculate_iou_between_stages R:84 and the any-overlap test of solve_overlapping P:289-292.
+ * ia / ib may be NULL (identity). */
+int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t na,
+                       const uint64_t *b, const int32_t *ib, int32_t nb, int64_t nw,
+                       int32_t *inter, void *stream);
+
+/* a9-a11: merge adjacency of `aggregate` P:100-146.  For every pair (i, j):
+ *   I = popcount(rows[i] & rows[j]);  iou = (float)I / ((float)area[i] + (float)area[j] - (float)I)
+ *   (IEEE float32 division; 0/0 = NaN compares false, P:149-166);
+ *   adj bit (i, j) = label_id[i] == label_id[j]  &&  iou > iou_thres   (float32 compare, P:120-122)
+ * label_id replaces the string compare of calculate_feature_similarity P:169-187.
+ * adj: uint64 [n_rows][ceil(n_rows/64)] bit matrix (bit j of row i), fully written.
+ * inter (optional, may be NULL): int32 [n_rows][n_rows] Gram matrix for tests/diagnostics. */
+int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *area,
+                        const int32_t *label_id, float iou_thres,
+                        uint64_t *adj, int32_t *inter, void *stream);
+
+/* a12: connected components of a symmetric bit adjacency (find_unconnected_subgraphs_tensor
+ * P:250-274 computes the transitive closure by n rounds of clamp(R@A + A); for the symmetric
+ * matrices produced by bff_merge_adjacency its rows are the connected components).
+ * One call = one propagation round: label[i] <- min(label[i], min over neighbours j of label[j]),
+ * followed by pointer jumping; *changed (int32, device) is set to 1 if any label moved.
+ * The host initialises label[i] = i, zeroes *changed and iterates until it stays 0; the result is
+ * label[i] = smallest member index of i's component. */
+int bff_components_round(const uint64_t *adj, int32_t n_nodes, const int32_t *label_in, int32_t *label_out,
+                         int32_t *changed, void *stream);
+
+/* a13: out[g] = OR of rows[members[group_offs[g] .. group_offs[g+1])]      (merge_masks P:219-224;
+ * also the `.any(dim=0)` merge of R:269). */
+int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int32_t *group_offs, const int32_t *members,
+                         int32_t n_groups, uint64_t *out, void *stream);
+
+/* a13: mean[g] = (((c[m0] + c[m1]) + c[m2]) ...) / len, every step rounded to the confidence dtype
+ * (P:225: python `sum(conf) / len(conf)` over 0-dim tensors).  dtype: 0 = float32, 1 = float16. */
+int bff_group_conf_mean(const void *conf, int32_t dtype, const int32_t *group_offs, const int32_t *members,
+                        int32_t n_groups, void *mean, void *stream);
+
+/* a16/a20: sequential row program applied independently to every word column.
+ * ops: int32 [n_ops][3] = (opcode, dst, src) executed in order;
+ *   opcode 0: rows[dst] &= ~rows[src]   (solve_overlapping P:295-299)
+ *   opcode 1: rows[dst] |=  rows[src]   (stage-1 duplicate merge R:248)
+ *   opcode 2: rows[dst]  =  rows[src] */
+int bff_apply_row_ops(uint64_t *rows, int64_t nw, const int32_t *ops, int32_t n_ops, void *stream);
+
+/* a16: rows[r] &= keep for r < n_rows                                                   (P:595) */
+int bff_and_rows(uint64_t *rows, int32_t n_rows, int64_t nw, const uint64_t *keep, void *stream);
+
+/* out[r] = rows[idx[r]] (row gather; P:601-607 row selection, R:310). */
+int bff_gather_rows(const uint64_t *rows, const int32_t *idx, int32_t n_out, int64_t nw, uint64_t *out,
+                    void *stream);
+
+/* bit rows <-> dense boolean rows (uint8 0/1, the layout of torch.bool), for the dict contract
+ * {"ins": bool (K,N)} (P:630-634, R:411). */
+int bff_unpack_rows(const uint64_t *rows, int32_t n_rows, int64_t nw, int64_t n_points, uint8_t *dense,
+                    void *stream);
+int bff_pack_rows(const uint8_t *dense, int32_t n_rows, int64_t n_points, int64_t nw, uint64_t *rows,
+                  void *stream);
+
+/* a18: 1-D RLE (Open3DIS stage-1 "ins") -> bit rows.  rle_decode R:26-39.  Same run layout as
+ * bff_rle_to_maskbits: row g owns runs [row_run_offs[g], row_run_offs[g+1]), sorted, disjoint. */
+int bff_rle_to_rows(const int32_t *run_start, const int32_t *run_end, const int32_t *row_run_offs,
+                    int32_t n_rows, int64_t n_points, int64_t nw, uint64_t *rows, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a14/a15 -- point filters.
+ * bff_count_lattice: presence[m * (v_max+1) + v] |= 1 for every point with (masked=m, viewed=v):
+ * the set of distinct (masked, viewed) pairs, from which the host forms the distinct float32 ratios
+ * masked/(viewed+1) and picks unique()[floor(t * n_unique)] exactly like P:571-576 (or P:513-518 with
+ * viewed == NULL, v = 0).  presence: uint8 [(m_max+1)*(v_max+1)], zeroed by the caller.
+ * bff_ratio_keep: keep bit n = masked[n] > 0 && !((float)masked[n] / ((float)viewed[n] + 1.0f) < thr)
+ * (P:571,578,583; viewed == NULL -> keep = masked > 0 && !(masked < thr), P:522). */
+int bff_count_lattice(const int32_t *masked, const int32_t *viewed, int64_t n_points,
+                      int32_t m_max, int32_t v_max, uint8_t *presence, void *stream);
+int bff_ratio_keep(const int32_t *masked, const int32_t *viewed, int64_t n_points, float thr, int32_t use_thr,
+                   int64_t nw, uint64_t *keep, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a21/a24 -- cosine similarity GEMM on the matrix cores (MFMA f16 -> f32).
+ *   cos[i][j] = <a_i, b_j> / (||a_i|| * ||b_j||), float32 accumulate and normalisation
+ * (compute_clip_similarity R:93-115; bbox_filter SEG:388-393).  a: f16 [na][dim], b: f16 [nb][dim],
+ * dim % 32 == 0, cos: float32 [na][nb]. */
+int bff_cosine_gemm_f16(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim,
+                        float *cos, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFF_HIP_H */

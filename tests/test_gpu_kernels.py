@@ -1,0 +1,329 @@
+"""GPU parity, kernel by kernel: every C-ABI entry point against the oracle / golden vectors.
+
+Bar: bit-exact for masks, counters, popcounts, adjacency and components; float32-exact for the
+confidence mean; 1e-4 absolute for the cosine GEMM (tolerance stated by BASELINE.json north_star).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+from oracle import projection_ref as pref, rle_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+Z = lambda name: np.load(os.path.join(gio.GOLDEN_DIR, name))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from beyond_fixed_forms_amd import _lib
+    _lib.load()
+    assert torch.cuda.is_available()
+    return _lib
+
+
+def unpack(rows, n):
+    """int64 bit rows (device) -> bool numpy (R,n), independent of bff_unpack_rows."""
+    b = rows.cpu().numpy().view(np.uint8)
+    return np.unpackbits(b, axis=-1, bitorder="little")[:, :n].astype(bool)
+
+
+def pack_np(dense):
+    n = dense.shape[1]
+    nw = (n + 63) // 64
+    pad = np.zeros((dense.shape[0], nw * 64), bool)
+    pad[:, :n] = dense
+    return torch.from_numpy(np.packbits(pad, axis=-1, bitorder="little").view(np.int64).copy()).to(DEV)
+
+
+def maskbits_from_dense(lib, masks_list, hw):
+    """list over views of dense (M,H*W) bool -> device maskbits via the RLE decode kernel."""
+    from beyond_fixed_forms_amd.scene import runs_from_rles
+    rles, voffs = [], [0]
+    for m in masks_list:
+        rles += rle_ref.rle_encode_batch_ref(torch.from_numpy(m))
+        voffs.append(voffs[-1] + m.shape[0])
+    wb = 32 if max(m.shape[0] for m in masks_list) <= 32 else 64
+    rs, re, offs = runs_from_rles(rles)
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).to(DEV)
+    out = torch.empty((len(masks_list), hw), dtype=torch.int32 if wb == 32 else torch.int64, device=DEV)
+    lib.rle_to_maskbits(t(rs), t(re), t(offs), t(voffs), len(masks_list), hw, wb, out)
+    return out, wb
+
+
+# ------------------------------------------------------------------ RLE decode (a1)
+@pytest.mark.parametrize("m,hw", [(1, 100), (5, 5000), (32, 2048 * 16 + 77), (33, 4099), (64, 2048 * 3), (7, 2048 * 17)])
+def test_rle_to_maskbits(lib, m, hw):
+    rng = np.random.default_rng(m * 1000 + hw)
+    dense = np.zeros((m, hw), bool)
+    for k in range(m):
+        x = rng.random(hw) < rng.choice([0.0, 0.02, 0.5, 1.0], p=[0.1, 0.4, 0.4, 0.1])
+        # long runs, some crossing the 2048-pixel chunk and the 16-chunk band boundaries
+        for _ in range(4):
+            a = int(rng.integers(0, hw)); b = min(hw, a + int(rng.integers(1, 5000)))
+            x[a:b] = True
+        dense[k] = x if rng.random() < 0.9 else False
+    dense[0, 0] = dense[0, -1] = True
+    bits, wb = maskbits_from_dense(lib, [dense], hw)
+    got = bits.cpu().numpy()[0].astype(np.uint64 if wb == 64 else np.uint32)
+    exp = np.zeros(hw, dtype=np.uint64)
+    for k in range(m):
+        exp |= dense[k].astype(np.uint64) << np.uint64(k)
+    assert np.array_equal(got.astype(np.uint64), exp)
+    # the oracle decoder agrees with the dense masks we encoded
+    dec = rle_ref.rle_decode_batch_ref(rle_ref.rle_encode_batch_ref(torch.from_numpy(dense))).numpy().astype(bool)
+    assert np.array_equal(dec, dense)
+
+
+def test_rle_unsorted_overlapping_runs_are_normalised(lib):
+    from beyond_fixed_forms_amd.scene import runs_from_rles
+    rle = dict(length=300, counts=np.array([50, 20, 10, 30, 60, 5, 290, 50]))   # unsorted, overlapping, clipped
+    rs, re, offs = runs_from_rles([rle])
+    exp = rle_ref.rle_decode_ref(rle).astype(bool)
+    got = np.zeros(300, bool)
+    for a, b in zip(rs, re):
+        got[a:b] = True
+    assert np.array_equal(got, exp) and np.all(rs[1:] >= re[:-1])
+    with pytest.raises(ValueError):
+        runs_from_rles([dict(length=10, counts=np.array([0, 3]))])
+
+
+# ------------------------------------------------------------------ projection sweep (a2-a7, a15)
+def run_view(lib, xyz, inv_pose, k33, depth, masks):
+    n = xyz.shape[0]
+    nw = (n + 63) // 64
+    n_pad = ((n + 1023) // 1024) * 1024
+    soa = np.zeros((3, n_pad)); soa[:, :n] = xyz.T
+    h, w = depth.shape
+    m = masks.shape[0]
+    bits, wb = maskbits_from_dense(lib, [masks.reshape(m, -1).astype(bool)], h * w)
+    i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)
+    rows = torch.empty((m, nw), dtype=torch.int64, device=DEV)
+    mc = torch.zeros(n, dtype=torch.int32, device=DEV)
+    vc = torch.zeros(n, dtype=torch.int32, device=DEV)
+    lib.project_views(torch.from_numpy(soa).to(DEV), n, torch.from_numpy(inv_pose.reshape(1, 16).copy()).to(DEV), k33,
+                      torch.from_numpy(depth.reshape(1, -1).copy()).to(DEV), i32([0]), h, w, 0.08, bits, wb,
+                      i32([0]), i32([0]), i32([m]), i32([1]), rows, mc, vc)
+    return unpack(rows, n), mc.cpu().numpy(), vc.cpu().numpy()
+
+
+@pytest.mark.parametrize("case", [str(c) for c in Z("proj_helpers.npz")["cases"]])
+def test_project_views_golden(lib, case):
+    """Against the reference's own outputs, incl. exact half pixels, +-ulp around the depth
+    threshold, z <= 0, z == 0 (NaN/inf -> INT64_MIN), out-of-bounds points and denormals."""
+    z = Z("proj_helpers.npz")
+    g = lambda k: z[f"{case}.{k}"]
+    n = g("xyz").shape[0]
+    masked, mc, vc = run_view(lib, g("xyz"), g("inv_pose"), g("K"), g("depth"), g("masks"))
+    exp = gio.unpack_bool_rows(g("masked"), n)
+    assert np.array_equal(vc.astype(bool), g("vis"))
+    assert np.array_equal(masked, exp)
+    assert np.array_equal(mc, exp.sum(0))
+
+
+def test_project_views_random_vs_c_oracle(lib):
+    """200k points, 6 frames, ScanNet-like intrinsics: pixel-exact against the fma-chain C oracle."""
+    from oracle import geom_fma
+    rng = np.random.default_rng(3)
+    n, h, w, m = 200_000, 240, 320, 9
+    xyz = rng.uniform(-4, 4, (n, 3))
+    k33 = np.array([[288.0123, 0.0, 159.5], [0.0, 288.0123, 119.5], [0.0, 0.0, 1.0]])
+    for f in range(6):
+        a = rng.uniform(-3, 3)
+        pose = np.eye(4)
+        pose[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+        pose[:3, 3] = rng.uniform(-1, 1, 3)
+        inv = np.linalg.inv(pose)
+        pts, pix, _ = geom_fma.view(xyz, inv, k33, np.zeros((h, w), np.float32))
+        depth = rng.uniform(0.5, 6, (h, w)).astype(np.float32)
+        ok = (pix[:, 0] >= 0) & (pix[:, 0] < w) & (pix[:, 1] >= 0) & (pix[:, 1] < h)
+        sel = ok & (rng.random(n) < 0.7)
+        depth[pix[sel, 1], pix[sel, 0]] = (pts[sel, 2] + rng.uniform(-0.1, 0.1, sel.sum())).astype(np.float32)
+        masks = rng.random((m, h, w)) < 0.3
+        _, _, vis = geom_fma.view(xyz, inv, k33, depth)
+        exp = pref.masked_points(pix, vis, masks.astype(np.float32))
+        masked, mc, vc = run_view(lib, xyz, inv, k33, depth, masks)
+        assert np.array_equal(vc.astype(bool), vis)
+        assert np.array_equal(masked, exp)
+        assert np.array_equal(mc, exp.sum(0))
+        assert vis.sum() > 1000
+
+
+# ------------------------------------------------------------------ bit-row primitives
+def random_rows(rng, r, n, p=0.1):
+    d = rng.random((r, n)) < p
+    return d
+
+
+@pytest.mark.parametrize("r,n", [(1, 1), (3, 64), (70, 1000), (130, 20_000)])
+def test_pack_unpack_popcount(lib, r, n):
+    rng = np.random.default_rng(r * n)
+    d = random_rows(rng, r, n, 0.3)
+    rows = lib.pack_rows(torch.from_numpy(d).to(DEV))
+    assert np.array_equal(unpack(rows, n), d)
+    assert torch.equal(rows, pack_np(d))                       # padding bits are zero
+    assert np.array_equal(lib.unpack_rows(rows, n).cpu().numpy(), d)
+    assert np.array_equal(lib.popcount_rows(rows).cpu().numpy(), d.sum(1))
+    idx = torch.tensor(rng.integers(0, r, 5), dtype=torch.int32, device=DEV)
+    assert np.array_equal(lib.popcount_rows(rows, idx).cpu().numpy(), d[idx.cpu().numpy()].sum(1))
+    assert np.array_equal(unpack(lib.gather_rows(rows, idx), n), d[idx.cpu().numpy()])
+
+
+@pytest.mark.parametrize("na,nb,n", [(1, 1, 10), (5, 70, 3000), (129, 65, 4097), (64, 64, 64 * 32)])
+def test_cross_popcount(lib, na, nb, n):
+    rng = np.random.default_rng(na + nb + n)
+    a, b = random_rows(rng, na, n, 0.2), random_rows(rng, nb, n, 0.3)
+    exp = a.astype(np.int32) @ b.astype(np.int32).T
+    assert np.array_equal(lib.cross_popcount(pack_np(a), pack_np(b)).cpu().numpy(), exp)
+    ia = torch.tensor(rng.integers(0, na, 7), dtype=torch.int32, device=DEV)
+    got = lib.cross_popcount(pack_np(a), pack_np(a), ia, ia).cpu().numpy()
+    sel = a[ia.cpu().numpy()].astype(np.int32)
+    assert np.array_equal(got, sel @ sel.T)
+
+
+@pytest.mark.parametrize("r,n", [(12, 300), (200, 5000), (130, 64)])
+def test_merge_adjacency_and_components(lib, r, n):
+    """Adjacency == same_label & (iou > f32(0.2)) of the oracle (P:100-146) incl. empty rows (NaN),
+    components == the oracle's closure components."""
+    rng = np.random.default_rng(r + n)
+    centres = rng.integers(0, n, 8)
+    d = np.zeros((r, n), bool)
+    for i in range(r):
+        c = centres[rng.integers(0, 8)]
+        wdt = int(rng.integers(1, max(2, n // 10)))
+        d[i, max(0, c - wdt): c + wdt] = True
+        d[i] &= rng.random(n) < 0.8
+    d[rng.integers(0, r, 3)] = False                              # empty masks -> NaN IoU
+    labels = [("a", "b")[int(x)] for x in rng.random(r) < 0.3]
+    t = torch.from_numpy(d)
+    iou = pref.pairwise_iou(t)
+    merge = pref.label_equality(labels) & (iou > 0.2)
+    rows = pack_np(d)
+    ids = {}
+    lid = torch.tensor([ids.setdefault(s, len(ids)) for s in labels], dtype=torch.int32, device=DEV)
+    area = lib.popcount_rows(rows)
+    adj, inter = lib.merge_adjacency(rows, area, lid, 0.2, want_inter=True)
+    assert np.array_equal(inter.cpu().numpy(), d.astype(np.int32) @ d.astype(np.int32).T)
+    assert np.array_equal(unpack(adj, r), merge.numpy())
+    from beyond_fixed_forms_amd.projection import groups_from_labels
+    lab = lib.components(adj).cpu().numpy()
+    got = groups_from_labels(lab, d.sum(1) > 0)
+    assert got == pref.connected_groups(merge.float())
+
+
+def test_components_long_chain(lib):
+    """A path graph of 3000 nodes (worst case for label propagation) + isolated nodes."""
+    n = 3000
+    adj = np.zeros((n, n), bool)
+    perm = np.random.default_rng(0).permutation(n)
+    for a, b in zip(perm[:-1], perm[1:]):
+        if a % 50 and b % 50:
+            adj[a, b] = adj[b, a] = True
+    adj[np.arange(n), np.arange(n)] = True
+    lab = lib.components(pack_np(adj)).cpu().numpy()
+    from beyond_fixed_forms_amd.projection import groups_from_labels
+    assert groups_from_labels(lab, np.ones(n, bool)) == pref.connected_groups(torch.from_numpy(adj).float())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_or_reduce_and_conf_mean(lib, dtype):
+    rng = np.random.default_rng(5)
+    r, n = 40, 777
+    d = random_rows(rng, r, n, 0.05)
+    groups = [[0, 5, 7], [1], [2, 3, 4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23], [39, 38]]
+    offs = torch.tensor(np.cumsum([0] + [len(g) for g in groups]), dtype=torch.int32, device=DEV)
+    mem = torch.tensor([i for g in groups for i in g], dtype=torch.int32, device=DEV)
+    out = lib.or_reduce_groups(pack_np(d), offs, mem)
+    assert np.array_equal(unpack(out, n), np.stack([d[g].any(0) for g in groups]))
+    conf = torch.from_numpy(rng.uniform(0.2, 0.5, r)).to(dtype)
+    got = lib.group_conf_mean(conf.to(DEV), offs, mem).cpu()
+    exp = torch.tensor([sum([conf[i] for i in g]) / len(g) for g in groups])     # P:225, sequential in dtype
+    assert got.dtype == dtype and torch.equal(got, exp)
+
+
+def test_row_ops_and_rows(lib):
+    rng = np.random.default_rng(8)
+    r, n = 6, 500
+    d = random_rows(rng, r, n, 0.4)
+    ops = [(0, 1, 0), (0, 2, 1), (1, 3, 2), (2, 4, 3), (0, 0, 5), (1, 5, 0)]
+    exp = d.copy()
+    for op, dst, src in ops:
+        exp[dst] = (exp[dst] & ~exp[src]) if op == 0 else (exp[dst] | exp[src]) if op == 1 else exp[src]
+    rows = pack_np(d)
+    lib.apply_row_ops(rows, torch.tensor(ops, dtype=torch.int32, device=DEV))
+    assert np.array_equal(unpack(rows, n), exp)
+    keep = rng.random(n) < 0.5
+    lib.and_rows(rows, pack_np(keep[None])[0])
+    assert np.array_equal(unpack(rows, n), exp & keep)
+
+
+def test_rle_to_rows_golden(lib):
+    from beyond_fixed_forms_amd.scene import runs_from_rles
+    z = Z("refine_helpers.npz")
+    rles = gio.unpack_rles(z["rle1d.len"], z["rle1d.counts"], z["rle1d.offs"])
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    for i, r in enumerate(rles):
+        rs, re, offs = runs_from_rles([r])
+        rows = lib.rle_to_rows(t(rs), t(re), t(offs), int(r["length"]))
+        assert np.array_equal(unpack(rows, int(r["length"]))[0], z[f"rle1d.dec{i}"].astype(bool)), i
+    rng = np.random.default_rng(1)
+    d = random_rows(rng, 9, 10_001, 0.3)
+    d[3] = False; d[4] = True
+    enc = rle_ref.rle_encode_batch_ref(torch.from_numpy(d))
+    rs, re, offs = runs_from_rles(enc)
+    assert np.array_equal(unpack(lib.rle_to_rows(t(rs), t(re), t(offs), 10_001), 10_001), d)
+
+
+@pytest.mark.parametrize("mode", ["ratio", "occurrence"])
+def test_point_filters(lib, mode):
+    """Threshold = unique()[floor(t * n_unique)] exactly as torch computes it (P:513-518, 571-576)."""
+    import math
+    from beyond_fixed_forms_amd.projection import _threshold_from_lattice
+    rng = np.random.default_rng(2)
+    n = 50_000
+    masked = rng.integers(0, 40, n) * (rng.random(n) < 0.4)
+    viewed = rng.integers(0, 25, n)
+    mt, vt = torch.tensor(masked, dtype=torch.float32), torch.tensor(viewed, dtype=torch.float32)
+    md = torch.tensor(masked, dtype=torch.int32, device=DEV)
+    vd = torch.tensor(viewed, dtype=torch.int32, device=DEV)
+    if mode == "ratio":
+        ratio = mt / (vt + 1)
+        uniq = ratio.unique()
+        thr = uniq[math.floor(0.38 * uniq.shape[0])]
+        mt[ratio < thr] = 0
+        pres = lib.count_lattice(md, vd, int(masked.max()), 24).cpu().numpy()
+        got_thr = _threshold_from_lattice(pres, 24, 0.38, ratio=True)
+        keep = lib.ratio_keep(md, vd, got_thr, True)
+    else:
+        uniq = mt.unique()
+        thr = uniq[math.floor(0.3 * uniq.shape[0])]
+        mt[mt < thr] = 0
+        pres = lib.count_lattice(md, None, int(masked.max()), 0).cpu().numpy()
+        got_thr = _threshold_from_lattice(pres, 0, 0.3, ratio=False)
+        keep = lib.ratio_keep(md, None, got_thr, True)
+    assert np.float32(got_thr) == thr.numpy()
+    assert np.array_equal(unpack(keep[None], n)[0], (mt > 0).numpy())
+    keep0 = lib.ratio_keep(md, None, 0.0, False)
+    assert np.array_equal(unpack(keep0[None], n)[0], masked > 0)
+
+
+@pytest.mark.parametrize("na,nb,dim", [(1, 198, 768), (37, 200, 64), (300, 198, 512), (16, 16, 32)])
+def test_cosine_gemm(lib, na, nb, dim):
+    """Config 5: CLIP-sized embeddings against a 200-label bank; |cos - f64 reference| <= 1e-4."""
+    g = torch.Generator().manual_seed(na * dim)
+    a = torch.randn(na, dim, generator=g).half()
+    b = torch.randn(nb, dim, generator=g).half()
+    got = lib.cosine_gemm_f16(a.to(DEV), b.to(DEV)).cpu().double()
+    ad, bd = a.double(), b.double()
+    exp = (ad @ bd.T) / (ad.norm(dim=1, keepdim=True) * bd.norm(dim=1, keepdim=True).T)
+    assert (got - exp).abs().max().item() <= 1e-4
+    # asymmetric exact-integer check of the MFMA fragment maps (would catch a transposed C write)
+    ai = torch.arange(na * dim).reshape(na, dim).remainder(7).half()
+    bi = torch.arange(nb * dim).reshape(nb, dim).remainder(5).add(1).half()
+    got = lib.cosine_gemm_f16(ai.to(DEV), bi.to(DEV)).cpu().double()
+    exp = (ai.double() @ bi.double().T) / (ai.double().norm(dim=1, keepdim=True) * bi.double().norm(dim=1, keepdim=True).T)
+    ok = torch.isfinite(exp)
+    assert (got[ok] - exp[ok]).abs().max().item() <= 1e-4
