@@ -1,0 +1,196 @@
+"""Headline benchmark: scenes/sec of 2D->3D projection + refinement (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" is one pass of the hot path over one batch = ONE scene per GPU of BASELINE config 2
+(200k points x 300 views @968x1296, 30 masks/view, stage-1 S1=100, 768-d text bank): RLE decode ->
+fused projection sweep -> IoU/label adjacency -> components -> merge -> ratio filter -> overlap/size
+filters -> refinement (stage-1 RLE decode, cross IoU, MFMA cosine, final masks) -> gather of the final
+bit-packed masks on rank 0.  Inputs are resident in HBM (uploaded before the timed region) in the
+reference's formats: float64 cloud, float32 depth, RLE runs.  Scenes shard one per GPU (weak scaling).
+
+The JSON line also carries `roofline` for the HBM-bound projection sweep (HIP-event timed on the
+launch stream, live) and `cpu_baseline`: the oracle (CPU restatement of the reference) timed on a
+bounded sample of the same scene on this box's host cores.
+"""
+from __future__ import annotations
+
+import os
+
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "16")
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
+import argparse
+import copy
+import json
+import sys
+import time
+import warnings
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from beyond_fixed_forms_amd import _lib, distributed as bdist  # noqa: E402
+from beyond_fixed_forms_amd.config import Config  # noqa: E402
+from beyond_fixed_forms_amd.projection import run_projection  # noqa: E402
+from beyond_fixed_forms_amd.refinement import TextSimilarity, refine_class  # noqa: E402
+from beyond_fixed_forms_amd.scene import prepare_scene  # noqa: E402
+from beyond_fixed_forms_amd.synthetic import SHAPES, make_scene, make_text_bank  # noqa: E402
+from beyond_fixed_forms_amd.timing import KernelTimers  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+QUERY = "table"
+
+
+def algorithmic_bytes(ds, n_frames_swept):
+    """SURVEY.md section 8(d) per-unit figures for one fused sweep launch: 24 B xyz + 4 B depth per
+    (frame, point); ceil(M/8) B mask-word gather per (mask-frame, point); every instance bit written
+    once (V*M*N/8); the two int32 counters read+written once (16 N).  Each (frame, point) is counted
+    once although the launch serves both the mask sweep and the viewed sweep of the reference."""
+    n = ds.n_points
+    mask_word = ds.word_bits // 8
+    return (n_frames_swept * n * 28 + ds.n_mask_frames * n * mask_word + ds.n_rows * n // 8 + 16 * n)
+
+
+def bank_encoder(bank, index):
+    def enc(text):
+        return bank[index[text.replace(" ", "_")]][None, :]
+    return enc
+
+
+def cpu_baseline(scene, cfg, enc, n_sample_views=12):
+    """Oracle (CPU restatement of the reference) on a bounded sample: the first `n_sample_views`
+    frames of the same scene at full N / HxW / M, whole path; scaled linearly to the scene's views."""
+    from oracle.projection_ref import project_scene_ref
+    from oracle.refinement_ref import refine_class_ref
+    torch.set_num_threads(16)
+    sub = copy.copy(scene)
+    sub.mask_2d = [dict(f) for f in scene.mask_2d[:n_sample_views]]
+    ratio = cfg.downsample_ratio
+    keep = {f["frame_id"] for f in sub.mask_2d}
+    sub.color_files = [f for f in scene.color_files if int(f[:-4]) < n_sample_views * ratio]
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = project_scene_ref(sub, cfg)
+        t1 = time.perf_counter()
+        try:
+            refine_class_ref([(sub.scene_id, sub.stage1, res)], cfg, QUERY, enc)
+        except IndexError:
+            pass
+    t2 = time.perf_counter()
+    n_views = len(scene.mask_2d)
+    est_scene_s = (t1 - t0) * n_views / max(1, len(sub.mask_2d)) + (t2 - t1)
+    return {"value": 1.0 / est_scene_s, "unit": "scenes/s", "cores": 16, "kind": "port",
+            "sample": f"oracle projection+refinement on {len(sub.mask_2d)} of {n_views} mask views and "
+                      f"{(len(sub.color_files) + ratio - 1) // ratio} viewed frames at full N/HxW/M ({t2 - t0:.1f} s CPU), "
+                      f"projection scaled linearly to {n_views} views; the reference's O(Ins^2) label loop and "
+                      f"O(Ins^4) closure are NOT included (oracle uses integer ids and a frontier search)",
+            "sample_seconds": t2 - t0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--shape", default="c2", choices=list(SHAPES))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    _lib.load()
+
+    # ---- one synthetic scene per rank (seed = rank), uploaded once: inputs resident in HBM
+    n, v, h, w, m = SHAPES[args.shape]
+    t0 = time.perf_counter()
+    scene = make_scene(args.shape, seed=rank, device=dev, query=QUERY)
+    cfg = Config.with_defaults(width_2d=scene.width, height_2d=scene.height)
+    ds = prepare_scene(scene, cfg, device=dev)
+    bank, index = make_text_bank(768, seed=0)
+    enc = bank_encoder(bank.float(), index)
+    sim = TextSimilarity(enc, dev)
+    t_setup = time.perf_counter() - t0
+    exchange = (lambda sims: bdist.exchange_similarities(sims, device=dev)) if world > 1 else None
+
+    timers = KernelTimers()
+
+    def step(tm=None):
+        res = run_projection(ds, cfg, timers=tm)
+        fin = refine_class([(scene.scene_id, scene.stage1, res)], cfg, QUERY, sim, dev, exchange_sims=exchange)
+        rows = fin[scene.scene_id].rows
+        if rows is None:
+            rows = torch.zeros((0, ds.nw), dtype=torch.int64, device=dev)
+        gathered = bdist.gather_final_rows(rows)
+        return res, fin, gathered
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, fin, gathered = step(timers)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ks = timers.summary()
+        n_swept = ds.n_frames
+        pv = ks["project_views"]
+        abytes = algorithmic_bytes(ds, n_swept)
+        achieved = abytes / (pv[2] * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                traffic = json.load(f).get(f"project_views_{args.shape}")
+        out = {
+            "metric": "scenes/sec (2D->3D projection+refinement), 200k pts x 300 views",
+            "value": world * args.steps / elapsed, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.shape}: 1 scene/GPU, {n} pts x {len(scene.mask_2d)} mask views + "
+                                   f"{ds.n_viewed} viewed frames @{h}x{w}, {m} masks/view (Ins={ds.n_rows}), "
+                                   f"stage-1 S1={len(scene.stage1['ins'])}, 198x768 f16 text bank",
+                       "scenes_per_step": world, "sharding": "one scene per GPU, RCCL gather of final masks"},
+            "roofline": {"bound": "hbm", "kernel": "project_views_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": pv[2], "launches": pv[0]},
+            "kernels_ms": {k: round(vv[2], 4) for k, vv in ks.items()},
+            "result": {"stage2_instances": int(res.rows.shape[0]),
+                       "final_masks": int(fin[scene.scene_id].rows.shape[0]) if fin[scene.scene_id].rows is not None else 0,
+                       "merged_groups": len(res.groups)},
+            "setup_s": round(t_setup, 1),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, cfg, enc)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

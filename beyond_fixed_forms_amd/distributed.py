@@ -1,0 +1,77 @@
+"""One process per GPU: scenes shard across ranks, RCCL carries only what the path really exchanges.
+
+The reference is a single process; scenes are independent through the whole
+projection stage, and refinement has exactly one cross-scene dependency: the similarity threshold is
+a percentile of the *set* of similarities over all scenes of the class (tools/refinement.py:316-324).
+So: scenes round-robin over ranks, one all-gather of the (tiny) per-rank similarity lists, and one
+gather of the final bit-packed masks to rank 0.  Over xGMI these messages are latency-bound (KBs to
+a few MB), so flat all-gather / gather calls are used, never a ring reduction.
+
+Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU tensors (tests).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+MAX_SIMS = 256          # a class meets at most one similarity per ScanNet200 label (198) per query
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_scenes(scene_ids: Sequence, rank: int = None, world_size: int = None, weights: Sequence[float] = None):
+    """Static partition: scenes sorted by descending weight (N*V; default: listing order) are dealt
+    round-robin.  Returns the indices owned by `rank`, in listing order."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    order = list(range(len(scene_ids)))
+    if weights is not None:
+        order.sort(key=lambda i: (-weights[i], i))
+    mine = [order[k] for k in range(rank, len(order), world_size)]
+    return sorted(mine)
+
+
+def exchange_similarities(local_sims: List[List[float]], device="cpu") -> List[List[float]]:
+    """All ranks' per-scene similarity lists -> one pooled list of lists (only the *set* of values
+    matters to the threshold, refinement.py:321-324).  One flat all-gather of MAX_SIMS+1 doubles."""
+    rank, ws = world()
+    if ws == 1:
+        return local_sims
+    uniq = sorted(set(s for sims in local_sims for s in sims))
+    if len(uniq) > MAX_SIMS:
+        raise ValueError(f"{len(uniq)} distinct similarities on one rank (> {MAX_SIMS})")
+    buf = torch.zeros(MAX_SIMS + 1, dtype=torch.float64, device=device)
+    buf[0] = len(uniq)
+    if uniq:
+        buf[1:1 + len(uniq)] = torch.tensor(uniq, dtype=torch.float64)
+    out = [torch.empty_like(buf) for _ in range(ws)]
+    dist.all_gather(out, buf)
+    return [o[1:1 + int(o[0].item())].tolist() for o in out]
+
+
+def gather_final_rows(rows: torch.Tensor, dst: int = 0):
+    """Gather every rank's final bit rows (int64 [R][nw], R and nw may differ per rank) on `dst`.
+    Returns, on dst, a list with one int64 [R_r][nw_r] tensor per rank; elsewhere None."""
+    rank, ws = world()
+    if ws == 1:
+        return [rows]
+    dev = rows.device
+    shape = torch.tensor([rows.shape[0], rows.shape[1]], dtype=torch.int64, device=dev)
+    shapes = [torch.empty_like(shape) for _ in range(ws)]
+    dist.all_gather(shapes, shape)
+    r_max = max(int(s[0]) for s in shapes)
+    w_max = max(int(s[1]) for s in shapes)
+    pad = torch.zeros((max(r_max, 1), max(w_max, 1)), dtype=torch.int64, device=dev)
+    pad[:rows.shape[0], :rows.shape[1]] = rows
+    bufs = [torch.empty_like(pad) for _ in range(ws)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return [b[:int(s[0]), :int(s[1])].clone() for b, s in zip(bufs, shapes)]

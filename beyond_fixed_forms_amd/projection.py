@@ -17,6 +17,7 @@ import torch
 
 from . import _lib
 from .scene import DEPTH_THRESH, DeviceScene, prepare_scene
+from .timing import span
 
 
 @dataclasses.dataclass
@@ -91,7 +92,7 @@ def _threshold_from_lattice(presence: np.ndarray, v_max: int, fraction: float, r
     return uniq[math.floor(fraction * uniq.shape[0])]
 
 
-def run_projection(ds: DeviceScene, cfg, debug_out: bool = False) -> Stage2Result:
+def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -> Stage2Result:
     """P:402-634 for one uploaded scene."""
     dev = ds.xyz.device
     dbg = {}
@@ -102,18 +103,20 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False) -> Stage2Resul
     n_mviews = ds.view_mask_offs.shape[0] - 1
     maskbits = torch.empty((n_mviews, ds.height * ds.width), device=dev,
                            dtype=torch.int32 if ds.word_bits == 32 else torch.int64)
-    _lib.rle_to_maskbits(ds.run_start, ds.run_end, ds.mask_run_offs, ds.view_mask_offs, n_mviews,
-                         ds.height * ds.width, ds.word_bits, maskbits)
+    with span(timers, "rle_to_maskbits"):
+        _lib.rle_to_maskbits(ds.run_start, ds.run_end, ds.mask_run_offs, ds.view_mask_offs, n_mviews,
+                             ds.height * ds.width, ds.word_bits, maskbits)
 
     # a2-a8 (+a15): one fused sweep over the frames (P:413-461 and P:538-567)
     rows = torch.empty((ds.n_rows, nw), dtype=torch.int64, device=dev)
     masked = torch.zeros(n, dtype=torch.int32, device=dev)                          # P:402
     viewed = torch.zeros(n, dtype=torch.int32, device=dev) if do_ratio else None    # P:537
     n_frames = ds.n_frames if do_ratio else ds.n_mask_frames
-    _lib.project_views(ds.xyz, n, ds.inv_pose[:n_frames], ds.cam_intr, ds.depth, ds.depth_index, ds.height,
-                       ds.width, DEPTH_THRESH, maskbits if n_mviews else None, ds.word_bits, ds.frame_mask,
-                       ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows if ds.n_rows else None,
-                       masked, viewed)
+    with span(timers, "project_views"):
+        _lib.project_views(ds.xyz, n, ds.inv_pose[:n_frames], ds.cam_intr, ds.depth, ds.depth_index, ds.height,
+                           ds.width, DEPTH_THRESH, maskbits if n_mviews else None, ds.word_bits, ds.frame_mask,
+                           ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows if ds.n_rows else None,
+                           masked, viewed)
     del maskbits
     if debug_out:
         dbg["raw_rows"], dbg["masked_counts_raw"] = rows, masked.clone()
@@ -122,8 +125,10 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False) -> Stage2Resul
 
     # a9-a12: IoU / label adjacency and its connected components (P:100-146, 250-274)
     area = _lib.popcount_rows(rows)
-    adj = _lib.merge_adjacency(rows, area, ds.label_id, cfg.iou_thres)
-    label = _lib.components(adj).cpu().numpy()
+    with span(timers, "merge_adjacency"):
+        adj = _lib.merge_adjacency(rows, area, ds.label_id, cfg.iou_thres)
+    with span(timers, "components"):
+        label = _lib.components(adj).cpu().numpy()
     area_h = area.cpu().numpy()
     self_loop = (area_h > 0) & bool(np.float32(1.0) > np.float32(cfg.iou_thres))
     comps = groups_from_labels(label, self_loop)
