@@ -1,0 +1,100 @@
+"""Disk formats of the reference <-> in-memory scene inputs (the file-level drop-in boundary).
+
+Reads exactly the files tools/projection_2d_to_3d.py reads (P:370-400, 422-436, 526-535) and
+tools/refinement.py reads (R:172-193), writes what they write (P:630-634, R:422-428 and the scene
+checkpoints P:320-334, R:41-55).  Depth decoding: the reference uses cv2.imread(IMREAD_UNCHANGED) /
+1000 and cv2.resize (bilinear); cv2 is used when importable, otherwise PIL decodes the 16-bit PNG and
+`resize_bilinear_f32` restates cv2's INTER_LINEAR (parity unpinned: no cv2 in the build container).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from .synthetic import SceneInputs
+
+DEPTH_SCALE = 1000            # hard-coded at P:346
+
+
+def resize_bilinear_f32(img: np.ndarray, width: int, height: int) -> np.ndarray:
+    """cv2.resize(img, (width, height)) with INTER_LINEAR for float32 input: half-pixel centres,
+    edge clamp, horizontal then vertical 2-tap passes in float32."""
+    h, w = img.shape
+    if (h, w) == (height, width):
+        return img.copy()
+    img = img.astype(np.float32, copy=False)
+
+    def taps(n_dst, n_src):
+        f = (np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        a = (f - i0).astype(np.float32)
+        a[i0 < 0] = 0.0
+        i0 = np.clip(i0, 0, n_src - 1)
+        i1 = np.clip(i0 + 1, 0, n_src - 1)
+        return i0, i1, a
+
+    x0, x1, ax = taps(width, w)
+    y0, y1, ay = taps(height, h)
+    rows = img[:, x0] * (np.float32(1) - ax) + img[:, x1] * ax
+    return rows[y0] * (np.float32(1) - ay)[:, None] + rows[y1] * ay[:, None]
+
+
+def load_depth(path: str, width: int, height: int) -> np.ndarray:
+    """P:432-436: 16-bit PNG -> float32 metres -> (height, width)."""
+    try:
+        import cv2  # noqa: F401
+        d = cv2.imread(path, cv2.IMREAD_UNCHANGED).astype(np.float32) / DEPTH_SCALE
+        return cv2.resize(d, (width, height))
+    except ImportError:
+        from PIL import Image
+        d = np.asarray(Image.open(path)).astype(np.float32) / DEPTH_SCALE
+        return resize_bilinear_f32(d, width, height)
+
+
+def load_scene(cfg, cls: str, scene_id: str) -> SceneInputs:
+    """Everything P:370-400 + the per-frame files of P:422-436 and P:526-563 for one scene."""
+    scene_dir = os.path.join(cfg.scene_2d_dir, scene_id)
+    cam_intr = np.loadtxt(os.path.join(scene_dir, "intrinsic", "intrinsic_color.txt"))          # P:376
+    points = np.load(os.path.join(cfg.scene_npy_dir, f"{scene_id}.npy"))                         # P:387
+    # the mask_2d file is the user's own upstream output (segmentation_2d.py:500-504): a pickled list of
+    # dicts holding numpy count arrays, loaded exactly as the reference does (P:396)
+    mask_2d = torch.load(os.path.join(cfg.mask_2d_dir, cls, f"{scene_id}.pth"), weights_only=False)
+    color_dir = os.path.join(scene_dir, "color")
+    color_files = [f for f in os.listdir(color_dir) if f.endswith(".jpg")] if os.path.isdir(color_dir) else []
+    from .scene import viewed_frame_ids
+    need = {fr["frame_id"][:-4] for fr in mask_2d}
+    if (not cfg.if_occurance_threshold) and cfg.if_detected_ratio_threshold:
+        need |= set(viewed_frame_ids(color_files, cfg.downsample_ratio))
+    w, h = int(cfg.width_2d), int(cfg.height_2d)
+    poses = {f: np.loadtxt(os.path.join(scene_dir, "pose", f"{f}.txt")) for f in need}           # P:422
+    depths = {f: load_depth(os.path.join(scene_dir, "depth", f"{f}.png"), w, h) for f in need}   # P:431-436
+    return SceneInputs(scene_id=scene_id, points=points, cam_intr=cam_intr, poses=poses, depths=depths,
+                       mask_2d=mask_2d, color_files=color_files, height=h, width=w)
+
+
+def scene_checkpoint_file(stage: str, cls: str) -> str:
+    """P:320-322 / R:41-43."""
+    return f"checkpoints/{stage}_checkpoint_{cls}.yaml"
+
+
+def read_scene_checkpoint(stage, cls):
+    p = scene_checkpoint_file(stage, cls)
+    if os.path.exists(p):
+        with open(p) as f:
+            return yaml.safe_load(f) or {}
+    return {}
+
+
+def write_scene_checkpoint(stage, cls, ckpt):
+    p = scene_checkpoint_file(stage, cls)
+    os.makedirs(os.path.dirname(p), exist_ok=True)       # the reference never creates it
+    with open(p, "w") as f:
+        yaml.safe_dump(ckpt, f)
+
+
+def save_result(result: dict, out_dir: str, cls: str, scene_id: str):
+    os.makedirs(os.path.join(out_dir, cls), exist_ok=True)
+    torch.save(result, os.path.join(out_dir, cls, f"{scene_id}.pth"))

@@ -1,0 +1,62 @@
+"""The N > 1 path on CPU: world_size 2, gloo.  Scenes shard across ranks, the similarity sets are
+all-gathered (the one exchange step of the path), final bit rows are gathered on rank 0."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from beyond_fixed_forms_amd import distributed as bd
+    from beyond_fixed_forms_amd.refinement import sim_threshold
+    scenes = [f"scene{i:04d}_00" for i in range(5)]
+    mine = bd.shard_scenes(scenes)
+    all_sims = {0: [0.31, 0.12], 1: [], 2: [0.12, 0.77, 0.5], 3: [0.05], 4: [0.31]}       # per scene
+    local = [all_sims[i] for i in mine]
+    pooled = bd.exchange_similarities(local)
+    thr = sim_threshold(pooled, 0.2)
+    rows = torch.full((rank + 1, 3 + rank), rank + 7, dtype=torch.int64)                 # ragged shapes per rank
+    gathered = bd.gather_final_rows(rows)
+    q.put((rank, mine, thr, None if gathered is None else [g.tolist() for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (r0, mine0, thr0, g0), (r1, mine1, thr1, g1) = out
+    assert mine0 == [0, 2, 4] and mine1 == [1, 3]
+    from beyond_fixed_forms_amd.refinement import sim_threshold
+    single = sim_threshold([[0.31, 0.12], [], [0.12, 0.77, 0.5], [0.05], [0.31]], 0.2)
+    assert thr0 == thr1 == single                                  # same threshold as the single-process class loop
+    assert g1 is None and g0 == [[[7] * 3], [[8] * 4, [8] * 4]]
+
+
+def test_shard_scenes_weighted():
+    from beyond_fixed_forms_amd.distributed import shard_scenes
+    ids = list("abcdef")
+    w = [5, 1, 9, 3, 7, 2]
+    parts = [shard_scenes(ids, r, 3, w) for r in range(3)]
+    assert sorted(i for p in parts for i in p) == list(range(6))
+    assert parts[0] == [2, 3] and parts[1] == [4, 5] and parts[2] == [0, 1]      # 9,3 | 7,2 | 5,1
+    assert shard_scenes(ids, 0, 1) == list(range(6))

@@ -1,0 +1,167 @@
+"""CPU tests of the host-side logic (no GPU, no compute calls into the HIP library)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+from oracle import projection_ref as pref, rle_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_loads_and_exports_every_declared_symbol():
+    from beyond_fixed_forms_amd import _lib
+    header = open(os.path.join(ROOT, "include", "bff_hip.h")).read()
+    declared = set(re.findall(r"\b(bff_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(_lib.SIGNATURES) | set(_lib.PLAIN), "python binding table out of sync with the header"
+    lib.bff_abi_version.restype = ctypes.c_int32
+    lib.bff_arch.restype = ctypes.c_char_p
+    assert lib.bff_abi_version() == _lib.ABI_VERSION and lib.bff_arch() == b"gfx950"
+
+
+def test_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument validation happens on the host before any launch."""
+    from beyond_fixed_forms_amd import _lib
+    lib = _lib.load()
+    assert lib.bff_popcount_rows(None, None, -1, 0, None, None) == -1
+    assert b"bad sizes" in lib.bff_last_error()
+    assert lib.bff_cosine_gemm_f16(None, 1, None, 1, 33, None, None) == -1
+    assert lib.bff_rle_to_maskbits(None, None, None, None, 1, 10, 48, None, None) == -1
+    assert lib.bff_popcount_rows(None, None, 0, 0, None, None) == 0          # empty work is fine
+
+
+def test_no_cpu_fallback():
+    from beyond_fixed_forms_amd import _lib
+    with pytest.raises(ValueError):
+        _lib.popcount_rows(torch.zeros((2, 2), dtype=torch.int64))            # CPU tensor is refused
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "beyond_fixed_forms_amd")
+    for name in os.listdir(pkg):
+        if name.endswith(".py"):
+            src = open(os.path.join(pkg, name)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), name
+
+
+def test_runs_from_rles_matches_reference_decoder():
+    from beyond_fixed_forms_amd.scene import runs_from_rles
+    z = np.load(os.path.join(gio.GOLDEN_DIR, "refine_helpers.npz"))
+    rles = gio.unpack_rles(z["rle1d.len"], z["rle1d.counts"], z["rle1d.offs"])
+    rs, re_, offs = runs_from_rles(rles)
+    for i, r in enumerate(rles):
+        got = np.zeros(int(r["length"]), np.uint8)
+        for a, b in zip(rs[offs[i]:offs[i + 1]], re_[offs[i]:offs[i + 1]]):
+            got[a:b] = 1
+        assert np.array_equal(got, z[f"rle1d.dec{i}"]), i
+        seg_s, seg_e = rs[offs[i]:offs[i + 1]], re_[offs[i]:offs[i + 1]]
+        assert np.all(seg_e > seg_s) and np.all(seg_s[1:] >= seg_e[:-1])
+    assert runs_from_rles([])[2].tolist() == [0]
+
+
+def test_groups_from_labels_matches_closure_components():
+    from beyond_fixed_forms_amd.projection import groups_from_labels
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        n = int(rng.integers(1, 60))
+        a = rng.random((n, n)) < 0.05
+        a = a | a.T
+        alive = rng.random(n) < 0.85
+        a[np.arange(n), np.arange(n)] = True
+        a[~alive] = False
+        a[:, ~alive] = False
+        exp = pref.connected_groups(torch.from_numpy(a).float())
+        # component label = smallest member index (what the device propagation converges to)
+        label = np.arange(n)
+        for comp in exp:
+            for i in comp:
+                label[i] = comp[0]
+        assert groups_from_labels(label.astype(np.int32), alive) == exp
+
+
+def test_threshold_from_lattice_equals_torch_unique():
+    import math
+    from beyond_fixed_forms_amd.projection import _threshold_from_lattice
+    rng = np.random.default_rng(1)
+    m = rng.integers(0, 30, 5000) * (rng.random(5000) < 0.5)
+    v = rng.integers(0, 12, 5000)
+    pres = np.zeros((m.max() + 1) * 12, np.uint8)
+    pres[m * 12 + v] = 1
+    ratio = torch.tensor(m, dtype=torch.float32) / (torch.tensor(v, dtype=torch.float32) + 1)
+    uniq = ratio.unique()
+    assert _threshold_from_lattice(pres, 11, 0.38, True) == uniq[math.floor(0.38 * len(uniq))].numpy()
+    cnt = torch.tensor(m, dtype=torch.float32).unique()
+    pres1 = np.zeros(m.max() + 1, np.uint8)
+    pres1[m] = 1
+    assert _threshold_from_lattice(pres1, 0, 0.3, False) == cnt[math.floor(0.3 * len(cnt))].numpy()
+
+
+def test_prepare_scene_frame_table_cpu():
+    """Frame table / run tables are built on the host; check them without touching a GPU."""
+    from beyond_fixed_forms_amd.config import Config
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    from beyond_fixed_forms_amd.synthetic import make_scene
+    sc = make_scene("tiny", seed=3, n_masks=70, n_views=3)
+    cfg = Config.with_defaults(width_2d=sc.width, height_2d=sc.height)
+    ds = prepare_scene(sc, cfg, device="cpu")
+    assert ds.word_bits == 64 and ds.n_rows == 70 * len(sc.mask_2d)
+    assert ds.frame_nmask.tolist()[:2] == [64, 6] and ds.frame_rowbase.tolist()[:3] == [0, 64, 70]
+    assert ds.frame_flags.tolist()[:2] == [1, 0]                     # a chunked frame is counted once
+    assert int(ds.frame_flags.sum()) == ds.n_viewed == 3
+    assert ds.xyz.shape[1] % 1024 == 0 and ds.nw == (sc.points.shape[0] + 63) // 64
+    assert np.allclose(ds.inv_pose[0].reshape(4, 4).numpy() @ sc.poses["0"], np.eye(4), atol=1e-12)
+    sc2 = make_scene("tiny", seed=3)
+    sc2.mask_2d[0]["segmented_frame_masks"][0]["length"] = 5
+    with pytest.raises(ValueError):
+        prepare_scene(sc2, Config.with_defaults(width_2d=sc2.width, height_2d=sc2.height), device="cpu")
+
+
+def test_disk_round_trip_and_cli_paths(tmp_path):
+    """The reference's directory layout -> load_scene gives back the same inputs (depth via 16-bit PNG)."""
+    from PIL import Image
+    from beyond_fixed_forms_amd import io
+    from beyond_fixed_forms_amd.config import Config
+    from beyond_fixed_forms_amd.synthetic import make_scene
+    sc = make_scene("tiny", seed=4)
+    cfg = Config.with_defaults(width_2d=sc.width, height_2d=sc.height, scene_2d_dir=str(tmp_path / "2d"),
+                               scene_npy_dir=str(tmp_path / "npy"), mask_2d_dir=str(tmp_path / "m2d"))
+    sd = tmp_path / "2d" / sc.scene_id
+    for sub in ("intrinsic", "pose", "depth", "color"):
+        (sd / sub).mkdir(parents=True)
+    (tmp_path / "npy").mkdir(); (tmp_path / "m2d" / "table").mkdir(parents=True)
+    np.savetxt(sd / "intrinsic" / "intrinsic_color.txt", sc.cam_intr)
+    np.save(tmp_path / "npy" / f"{sc.scene_id}.npy", sc.points)
+    for f in sc.color_files:
+        (sd / "color" / f).write_bytes(b"")
+    for fid, pose in sc.poses.items():
+        np.savetxt(sd / "pose" / f"{fid}.txt", pose)
+        mm = np.round(sc.depths[fid].astype(np.float64) * 1000).astype(np.uint16)
+        Image.fromarray(mm).save(sd / "depth" / f"{fid}.png")
+    torch.save(sc.mask_2d, tmp_path / "m2d" / "table" / f"{sc.scene_id}.pth")
+    got = io.load_scene(cfg, "table", sc.scene_id)
+    assert np.array_equal(got.points, sc.points) and np.allclose(got.cam_intr, sc.cam_intr)
+    for fid in sc.poses:
+        assert np.array_equal(got.depths[fid], sc.depths[fid])           # same size -> resize is the identity
+        assert np.allclose(got.poses[fid], sc.poses[fid])
+    assert sorted(got.color_files) == sorted(sc.color_files) and len(got.mask_2d) == len(sc.mask_2d)
+    up = io.resize_bilinear_f32(sc.depths["0"], 2 * sc.width, 2 * sc.height)
+    assert up.shape == (2 * sc.height, 2 * sc.width) and up.dtype == np.float32
+    assert abs(float(up.mean()) - float(sc.depths["0"].mean())) < 0.02
+    assert io.scene_checkpoint_file("refinement", "table") == "checkpoints/refinement_checkpoint_table.yaml"
+
+
+def test_sim_threshold_semantics():
+    from beyond_fixed_forms_amd.refinement import sim_threshold
+    assert sim_threshold([[0.5, 0.1], [], [0.1, 0.9, 0.3]], 0.2) == 0.1        # sorted set: .1 .3 .5 .9 -> [0]
+    assert sim_threshold([[0.5, 0.1], [0.9, 0.3, 0.7]], 0.2) == 0.3            # 5 values -> index 1
+    with pytest.raises(IndexError):
+        sim_threshold([[]], 0.2)
