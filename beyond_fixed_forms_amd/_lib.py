@@ -24,7 +24,9 @@ SIGNATURES = {
     "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P],
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
-    "bff_merge_adjacency": [_P, _I, _L, _P, _P, _F, _P, _P, _P],
+    "bff_row_stats": [_P, _I, _L, _P, _P, _P, _P],
+    "bff_merge_adjacency": [_P, _I, _L, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "bff_permute_bits": [_P, _I, _L, _P, _L, _L, _P, _P],
     "bff_components_round": [_P, _I, _P, _P, _P, _P],
     "bff_or_reduce_groups": [_P, _L, _P, _P, _I, _P, _P],
     "bff_group_conf_mean": [_P, _I, _P, _P, _I, _P, _P],
@@ -38,7 +40,8 @@ SIGNATURES = {
     "bff_ratio_keep": [_P, _P, _L, _F, _I, _L, _P, _P],
     "bff_cosine_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
 }
-PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, [])}
+PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
+         "bff_chunk_mask_words": (c_int32, [c_int64])}
 ABI_VERSION = 1
 
 
@@ -135,14 +138,37 @@ def cross_popcount(a, b, ia=None, ib=None):
     return out
 
 
-def merge_adjacency(rows, area, label_id, iou_thres, want_inter=False):
+def row_stats(rows):
+    """-> (area i32 [R], mean_word i32 [R], chunk_mask i64 [R][mw])."""
+    n = rows.shape[0]
+    mw = load().bff_chunk_mask_words(rows.shape[1])
+    area = torch.empty(n, dtype=i32, device=rows.device)
+    mean_word = torch.empty(n, dtype=i32, device=rows.device)
+    cmask = torch.empty((n, max(mw, 1)), dtype=i64, device=rows.device)
+    call("bff_row_stats", _ptr(rows, i64), n, rows.shape[1], _ptr(area), _ptr(mean_word), _ptr(cmask))
+    return area, mean_word, cmask
+
+
+def merge_adjacency(rows, area, label_id, iou_thres, order=None, chunk_mask=None, want_inter=False):
+    """Adjacency bit matrix indexed by position in `order` (identity when None)."""
     n = rows.shape[0]
     aw = (n + 63) // 64
     adj = torch.empty((n, aw), dtype=i64, device=rows.device)
     inter = torch.empty((n, n), dtype=i32, device=rows.device) if want_inter else None
-    call("bff_merge_adjacency", _ptr(rows, i64), n, rows.shape[1], _ptr(area, i32), _ptr(label_id, i32),
-         float(iou_thres), _ptr(adj), _ptr(inter))
+    tmask = None
+    if chunk_mask is not None:
+        tmask = torch.empty((aw, chunk_mask.shape[1]), dtype=i64, device=rows.device)
+    call("bff_merge_adjacency", _ptr(rows, i64), n, rows.shape[1], _ptr(order, i32), _ptr(chunk_mask, i64),
+         _ptr(tmask), _ptr(area, i32), _ptr(label_id, i32), float(iou_thres), _ptr(adj), _ptr(inter))
     return (adj, inter) if want_inter else adj
+
+
+def permute_bits(rows, idx, n_out):
+    """out[r] bit o = rows[r] bit idx[o]."""
+    nw_out = (n_out + 63) // 64
+    out = torch.empty((rows.shape[0], nw_out), dtype=i64, device=rows.device)
+    call("bff_permute_bits", _ptr(rows, i64), rows.shape[0], rows.shape[1], _ptr(idx, i32), n_out, nw_out, _ptr(out))
+    return out
 
 
 def components(adj, max_rounds=10_000):

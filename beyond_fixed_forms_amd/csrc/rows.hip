@@ -97,9 +97,72 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
         }
 }
 
-// Upper-triangular tile pairs of the symmetric Gram matrix; the epilogue applies the reference's
-// float32 IoU test and emits adjacency words for the tile and its mirror image.
+// ---- row statistics for the block-sparse Gram -------------------------------------------------
+// Per row: popcount, occupancy mask over chunks of kCW words, and the mean word position of its set
+// bits (sort key that brings rows covering the same region of the -- spatially sorted -- cloud together).
+constexpr int kCW = 8;        // words per chunk (512 points)
+
+__global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restrict__ rows, int64_t nw, int mw,
+                                                         int32_t *__restrict__ area, int32_t *__restrict__ mean_word,
+                                                         uint64_t *__restrict__ cmask)
+{
+    extern __shared__ uint64_t s_cm[];                 // mw words
+    __shared__ int part[4];
+    __shared__ unsigned long long psum[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const uint64_t *row = rows + (int64_t)r * nw;
+    for (int i = tid; i < mw; i += 256) s_cm[i] = 0;
+    __syncthreads();
+    int s = 0;
+    unsigned long long ws = 0;
+    for (int64_t w = tid; w < nw; w += 256) {
+        const uint64_t v = row[w];
+        if (v) {
+            const int c = (int)(w / kCW);
+            atomicOr((unsigned long long *)&s_cm[c >> 6], 1ull << (c & 63));
+            const int pc = popc64(v);
+            s += pc;
+            ws += (unsigned long long)pc * (unsigned long long)w;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { s += __shfl_down(s, d); ws += __shfl_down(ws, d); }
+    if (lane_id() == 0) { part[tid >> 6] = s; psum[tid >> 6] = ws; }
+    __syncthreads();
+    for (int i = tid; i < mw; i += 256) cmask[(int64_t)r * mw + i] = s_cm[i];
+    if (tid == 0) {
+        const int a = part[0] + part[1] + part[2] + part[3];
+        const unsigned long long t = psum[0] + psum[1] + psum[2] + psum[3];
+        area[r] = a;
+        mean_word[r] = a ? (int32_t)(t / (unsigned long long)a) : 0x7fffffff;   // empty rows sort last
+    }
+}
+
+// tmask[t] = OR of the chunk masks of the 64 rows order[64t .. 64t+63]
+__global__ void tile_masks_kernel(const uint64_t *__restrict__ cmask, const int32_t *__restrict__ order, int n,
+                                  int mw, uint64_t *__restrict__ tmask)
+{
+    const int t = blockIdx.x;
+    for (int i = threadIdx.x; i < mw; i += blockDim.x) {
+        uint64_t v = 0;
+        for (int k = 0; k < kT; ++k) {
+            const int r = t * kT + k;
+            if (r < n) v |= cmask[(int64_t)(order ? order[r] : r) * mw + i];
+        }
+        tmask[(int64_t)t * mw + i] = v;
+    }
+}
+
+// Upper-triangular tile pairs of the symmetric Gram matrix.  Tile (bi, bj) covers rows
+// order[64 bi ..] x order[64 bj ..]; with tile chunk masks it visits only the chunks of kCW words
+// that both tiles occupy (four chunks = 32 words per LDS stage), otherwise every word.  The epilogue
+// applies the reference's float32 IoU test and emits adjacency words for the tile and its mirror
+// image, indexed by position in `order`.
+constexpr int kMaxChunks = 4096;     // chunk list capacity (LDS): N <= 4096*512 = 2.1 M points per call
+
 __global__ __launch_bounds__(256) void merge_adjacency_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
+                                                               const int32_t *__restrict__ order,
+                                                               const uint64_t *__restrict__ tmask, int mw,
                                                                const int32_t *__restrict__ area,
                                                                const int32_t *__restrict__ label_id, float thr,
                                                                uint64_t *__restrict__ adj, int aw,
@@ -107,21 +170,78 @@ __global__ __launch_bounds__(256) void merge_adjacency_kernel(const uint64_t *__
 {
     __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
     __shared__ uint8_t flag[kT][kT + 4];
+    __shared__ uint16_t clist[kMaxChunks];
+    __shared__ int s_cnt;
     // linear upper-triangular index -> (bi <= bj)
     int t = blockIdx.x, bi = 0;
     while (t >= n_tiles - bi) { t -= n_tiles - bi; ++bi; }
     const int bj = bi + t;
     const int i0 = bi * kT, j0 = bj * kT;
-    int acc[4][4];
-    tile_popcount(rows, nullptr, n, i0, rows, nullptr, n, j0, nw, sa, sb, acc);
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int n_chunks = (int)((nw + kCW - 1) / kCW);
+
+    // ---- chunks to visit
+    if (tid < kWave) {
+        int base = 0;
+        for (int m = 0; m < (n_chunks + 63) / 64; ++m) {
+            const uint64_t bits = tmask ? (tmask[(int64_t)bi * mw + m] & tmask[(int64_t)bj * mw + m]) : ~0ull;
+            const int c = m * 64 + tid;
+            const bool on = ((bits >> tid) & 1) && c < n_chunks;
+            const uint64_t bal = __ballot(on);
+            if (on) clist[base + __popcll(bal & ((1ull << tid) - 1))] = (uint16_t)c;
+            base += __popcll(bal);
+        }
+        if (tid == 0) s_cnt = base;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+
+    int acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+    if (cnt) {
+        const int lk = tid & (kKW - 1), lr = tid >> 5;      // loader: staged word lk of rows lr, lr+8, ...
+        const int slot = lk / kCW, cw = lk % kCW;
+        const uint64_t *pa[8];
+        const uint64_t *pb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ra = i0 + lr + 8 * q, rb = j0 + lr + 8 * q;
+            pa[q] = ra < n ? rows + (int64_t)(order ? order[ra] : ra) * nw : nullptr;
+            pb[q] = rb < n ? rows + (int64_t)(order ? order[rb] : rb) * nw : nullptr;
+        }
+        for (int g = 0; g < cnt; g += kKW / kCW) {
+            const int64_t w = (g + slot < cnt) ? (int64_t)clist[g + slot] * kCW + cw : nw;
+            const bool kin = w < nw;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                sa[lk][lr + 8 * q] = (kin && pa[q]) ? pa[q][w] : 0;
+                sb[lk][lr + 8 * q] = (kin && pb[q]) ? pb[q][w] : 0;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int kk = 0; kk < kKW; ++kk) {
+                uint64_t av[4], bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { av[r] = sa[kk][ti * 4 + r]; bv[r] = sb[kk][tj * 4 + r]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[r][c] += popc64(av[r] & bv[c]);
+            }
+            __syncthreads();
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int i = i0 + ti * 4 + r, j = j0 + tj * 4 + c;
+            const int si = i0 + ti * 4 + r, sj = j0 + tj * 4 + c;
             bool ok = false;
-            if (i < n && j < n) {
+            if (si < n && sj < n) {
+                const int i = order ? order[si] : si, j = order ? order[sj] : sj;
                 const float fi = (float)acc[r][c];
                 const float uni = (float)area[i] + (float)area[j] - fi;
                 const float iou = __fdiv_rn(fi, uni);           // 0/0 -> NaN -> compares false
@@ -149,6 +269,20 @@ __global__ __launch_bounds__(256) void merge_adjacency_kernel(const uint64_t *__
             adj[(int64_t)j * aw + bi] = w;
         }
     }
+}
+
+// out bit o of row r = in bit idx[o] of row r  (bit gather; undoes the spatial point sort)
+__global__ void permute_bits_kernel(const uint64_t *__restrict__ in, int64_t nw_in, const int32_t *__restrict__ idx,
+                                    int64_t n_out, int64_t nw_out, uint64_t *__restrict__ out)
+{
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bit = false;
+    if (o < n_out) {
+        const int s = idx[o];
+        bit = (in[(int64_t)blockIdx.y * nw_in + (s >> 6)] >> (s & 63)) & 1;
+    }
+    const uint64_t bal = __ballot(bit);
+    if (lane_id() == 0 && (o >> 6) < nw_out) out[(int64_t)blockIdx.y * nw_out + (o >> 6)] = bal;
 }
 
 // ---- group OR / confidence mean ---------------------------------------------------------------
@@ -286,19 +420,53 @@ extern "C" int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t 
     return launched("bff_cross_popcount");
 }
 
-extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *area,
+extern "C" int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *area, int32_t *mean_word,
+                             uint64_t *chunk_mask, void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_row_stats: bad sizes");
+    if (n_rows == 0) return BFF_OK;
+    BFF_REQUIRE(rows && area && mean_word && chunk_mask, "bff_row_stats: null pointer");
+    const int n_chunks = (int)ceil_div(nw, kCW);
+    BFF_LIMIT(n_chunks <= kMaxChunks, "bff_row_stats: more than %d chunks (N > %d points)", kMaxChunks, kMaxChunks * kCW * 64);
+    const int mw = (int)ceil_div(n_chunks, 64);
+    row_stats_kernel<<<n_rows, 256, mw * sizeof(uint64_t), as_stream(stream)>>>(rows, nw, mw, area, mean_word, chunk_mask);
+    return launched("bff_row_stats");
+}
+
+extern "C" int bff_chunk_mask_words(int64_t nw) { return (int)ceil_div(ceil_div(nw, kCW), 64); }
+
+extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
+                                   const uint64_t *chunk_mask, uint64_t *tile_mask, const int32_t *area,
                                    const int32_t *label_id, float iou_thres, uint64_t *adj, int32_t *inter,
                                    void *stream)
 {
     BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_merge_adjacency: bad sizes");
     if (n_rows == 0) return BFF_OK;
     BFF_REQUIRE(rows && area && label_id && adj, "bff_merge_adjacency: null pointer");
+    BFF_REQUIRE((chunk_mask == nullptr) == (tile_mask == nullptr), "bff_merge_adjacency: chunk_mask and tile_mask go together");
     const int nt = (int)ceil_div(n_rows, kT);
     BFF_LIMIT((int64_t)nt * (nt + 1) / 2 < (1ll << 31), "bff_merge_adjacency: too many rows");
+    const int n_chunks = (int)ceil_div(nw, kCW);
+    BFF_LIMIT(n_chunks <= kMaxChunks, "bff_merge_adjacency: more than %d chunks (N > %d points)", kMaxChunks, kMaxChunks * kCW * 64);
+    const int mw = (int)ceil_div(n_chunks, 64);
+    // pairs with an empty intersection have IoU 0 (or NaN): they can only be skipped when 0 > thr is false
+    const bool sparse = chunk_mask && !(0.0f > iou_thres);
+    if (sparse) tile_masks_kernel<<<nt, 64, 0, as_stream(stream)>>>(chunk_mask, order, n_rows, mw, tile_mask);
     const int aw = nt;   // ceil(n_rows/64) words per adjacency row
     merge_adjacency_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, as_stream(stream)>>>(
-        rows, n_rows, nw, area, label_id, iou_thres, adj, aw, inter, nt);
+        rows, n_rows, nw, order, sparse ? tile_mask : nullptr, mw, area, label_id, iou_thres, adj, aw, inter, nt);
     return launched("bff_merge_adjacency");
+}
+
+extern "C" int bff_permute_bits(const uint64_t *rows_in, int32_t n_rows, int64_t nw_in, const int32_t *idx,
+                                int64_t n_out, int64_t nw_out, uint64_t *rows_out, void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && n_out >= 0 && nw_out == ceil_div(n_out, 64) && nw_in >= 0, "bff_permute_bits: bad sizes");
+    if (n_rows == 0 || n_out == 0) return BFF_OK;
+    BFF_REQUIRE(rows_in && idx && rows_out, "bff_permute_bits: null pointer");
+    dim3 grid((unsigned)ceil_div(nw_out * 64, 256), (unsigned)n_rows);
+    permute_bits_kernel<<<grid, 256, 0, as_stream(stream)>>>(rows_in, nw_in, idx, n_out, nw_out, rows_out);
+    return launched("bff_permute_bits");
 }
 
 extern "C" int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int32_t *group_offs,

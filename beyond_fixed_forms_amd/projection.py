@@ -53,29 +53,26 @@ def _empty(ds: DeviceScene, debug) -> Stage2Result:
                         torch.zeros(0, device=ds.xyz.device), [], [], debug)
 
 
-def groups_from_labels(label: np.ndarray, has_self_loop: np.ndarray):
-    """Component labels (smallest member index) -> the list find_unconnected_subgraphs_tensor
-    returns (P:262-274): components in order of their smallest index, members ascending; a node
-    whose adjacency row is empty (no self loop: empty mask, IoU NaN) yields an empty list."""
-    n = label.shape[0]
-    order = np.argsort(label, kind="stable")           # members of a component, ascending, grouped by root
-    sl = has_self_loop[order]
-    lab_sorted = label[order]
-    comps = {}
-    if n:
-        cut = np.flatnonzero(np.diff(lab_sorted)) + 1
-        for seg in np.split(np.arange(n), cut):
-            root = int(lab_sorted[seg[0]])
-            members = order[seg][sl[seg]]
-            if members.size:
-                comps[root] = members.tolist()
-    out = []
-    for i in range(n):
-        if not has_self_loop[i]:
-            out.append([])
-        elif i in comps:
-            out.append(comps[i])
-    return out
+def groups_from_labels(comp: np.ndarray, has_self_loop: np.ndarray, min_members: int = 0):
+    """Component ids (any integer naming the component of node i) -> the list
+    find_unconnected_subgraphs_tensor returns (P:262-274), already filtered by
+    len >= min_members (P:203): components in order of their smallest member, members ascending; a
+    node whose adjacency row is empty (no self loop: empty mask, IoU NaN) yields an empty list."""
+    n = comp.shape[0]
+    idx = np.flatnonzero(has_self_loop)
+    out = []                                     # (first index, members)
+    if idx.size:
+        order = idx[np.argsort(comp[idx], kind="stable")]       # grouped by component, members ascending
+        cs = comp[order]
+        cut = np.flatnonzero(np.diff(cs)) + 1
+        starts = np.concatenate([[0], cut])
+        ends = np.concatenate([cut, [order.size]])
+        big = np.flatnonzero(ends - starts >= max(min_members, 1))
+        out = [(int(order[starts[g]]), order[starts[g]:ends[g]].tolist()) for g in big]
+    if min_members <= 0:                         # only then do the empty components survive the filter
+        out += [(int(i), []) for i in np.flatnonzero(~has_self_loop)]
+    out.sort(key=lambda kv: kv[0])
+    return [m for _, m in out]
 
 
 def _threshold_from_lattice(presence: np.ndarray, v_max: int, fraction: float, ratio: bool) -> np.float32:
@@ -118,21 +115,29 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -
                            ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows if ds.n_rows else None,
                            masked, viewed)
     del maskbits
+    # per-point arrays and bit rows are in the (spatially sorted) device point order; `unsorted` maps
+    # bit rows back to the caller's point order
+    unsorted = (lambda r: _lib.permute_bits(r, ds.unsort, n)) if ds.unsort is not None else (lambda r: r)
     if debug_out:
-        dbg["raw_rows"], dbg["masked_counts_raw"] = rows, masked.clone()
+        back = (lambda v: v[ds.unsort.long()]) if ds.unsort is not None else (lambda v: v.clone())
+        dbg["raw_rows"], dbg["masked_counts_raw"] = unsorted(rows), back(masked)
     if ds.n_rows == 0:                                                              # P:465-478
         return _empty(ds, dbg)
 
-    # a9-a12: IoU / label adjacency and its connected components (P:100-146, 250-274)
-    area = _lib.popcount_rows(rows)
+    # a9-a12: IoU / label adjacency and its connected components (P:100-146, 250-274).  Rows are tiled in
+    # the order (label, mean position of the row's bits) so that a tile's rows occupy few chunks.
+    with span(timers, "row_stats"):
+        area, mean_word, cmask = _lib.row_stats(rows)
+        order = torch.argsort((ds.label_id.to(torch.int64) << 32) | mean_word.to(torch.int64)).to(torch.int32)
     with span(timers, "merge_adjacency"):
-        adj = _lib.merge_adjacency(rows, area, ds.label_id, cfg.iou_thres)
+        adj = _lib.merge_adjacency(rows, area, ds.label_id, cfg.iou_thres, order=order, chunk_mask=cmask)
     with span(timers, "components"):
-        label = _lib.components(adj).cpu().numpy()
-    area_h = area.cpu().numpy()
+        label_pos = _lib.components(adj)                     # component id per position in `order`
+        comp = torch.empty_like(label_pos)
+        comp[order.long()] = label_pos
+        comp_h, area_h = comp.cpu().numpy(), area.cpu().numpy()
     self_loop = (area_h > 0) & bool(np.float32(1.0) > np.float32(cfg.iou_thres))
-    comps = groups_from_labels(label, self_loop)
-    groups = [g for g in comps if len(g) >= cfg.min_aggragated_masks]               # P:203
+    groups = groups_from_labels(comp_h, self_loop, cfg.min_aggragated_masks)        # P:203
     dbg["groups"] = groups
     merged = [g for g in groups if g != []]                                         # P:216-217
     if not merged:                                                                  # P:230-236, 496-509
@@ -163,7 +168,7 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -
         keep = _lib.ratio_keep(masked, viewed, thr, True)
         dbg["thr"] = float(thr)
         if debug_out:
-            dbg["viewed_counts"] = viewed
+            dbg["viewed_counts"] = back(viewed)
     else:
         keep = _lib.ratio_keep(masked, None, 0.0, False)
 
@@ -189,7 +194,7 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -
     keep_rows = (after_t > cfg.remove_small_masks) & (after_t > cfg.remove_filtered_masks * before_t)
     idx = torch.nonzero(keep_rows).view(-1).to(torch.int32)
     dbg.update(before=before_t, after=after_t, keep=keep_rows)
-    out_rows = _lib.gather_rows(agg, idx.to(dev)) if idx.numel() else agg[:0]
+    out_rows = unsorted(_lib.gather_rows(agg, idx.to(dev))) if idx.numel() else agg[:0]
     out_conf = conf[keep_rows.to(dev)]
     out_labels = [c for c, kk in zip(agg_labels, keep_rows.tolist()) if kk]
     return Stage2Result(ds.scene_id, n, out_rows, out_conf, out_labels, groups, dbg)

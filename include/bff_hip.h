@@ -108,16 +108,35 @@ int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t na,
                        const uint64_t *b, const int32_t *ib, int32_t nb, int64_t nw,
                        int32_t *inter, void *stream);
 
+/* Per-row statistics that make the Gram block-sparse: area[r] = popcount(row r); mean_word[r] = mean word
+ * index of its set bits (INT32_MAX for an empty row; a sort key that groups rows covering the same part of
+ * the cloud when the points are spatially sorted); chunk_mask[r] = occupancy bits over chunks of 8 words
+ * (512 points), bff_chunk_mask_words(nw) uint64 words per row. */
+int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *area, int32_t *mean_word,
+                  uint64_t *chunk_mask, void *stream);
+int bff_chunk_mask_words(int64_t nw);
+
 /* a9-a11: merge adjacency of `aggregate` P:100-146.  For every pair (i, j):
  *   I = popcount(rows[i] & rows[j]);  iou = (float)I / ((float)area[i] + (float)area[j] - (float)I)
  *   (IEEE float32 division; 0/0 = NaN compares false, P:149-166);
- *   adj bit (i, j) = label_id[i] == label_id[j]  &&  iou > iou_thres   (float32 compare, P:120-122)
+ *   adjacent = label_id[i] == label_id[j]  &&  iou > iou_thres   (float32 compare, P:120-122)
  * label_id replaces the string compare of calculate_feature_similarity P:169-187.
- * adj: uint64 [n_rows][ceil(n_rows/64)] bit matrix (bit j of row i), fully written.
- * inter (optional, may be NULL): int32 [n_rows][n_rows] Gram matrix for tests/diagnostics. */
-int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *area,
+ * `order` (int32 [n_rows], may be NULL = identity) is the order in which rows are tiled: tile t holds rows
+ * order[64t .. 64t+63].  adj: uint64 [n_rows][ceil(n_rows/64)], bit q of row p <=> rows order[p] and
+ * order[q] are adjacent (i.e. indexed by POSITION in `order`), fully written.
+ * chunk_mask (from bff_row_stats) + tile_mask (scratch, uint64 [ceil(n_rows/64)][bff_chunk_mask_words(nw)])
+ * enable chunk skipping: a 64x64 tile pair only visits chunks both tiles occupy (exact: skipped words
+ * contribute 0 to every intersection); both NULL = visit every word.
+ * inter (optional, may be NULL): int32 [n_rows][n_rows] Gram matrix in ROW index space, for tests. */
+int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
+                        const uint64_t *chunk_mask, uint64_t *tile_mask, const int32_t *area,
                         const int32_t *label_id, float iou_thres,
                         uint64_t *adj, int32_t *inter, void *stream);
+
+/* rows_out[r] bit o = rows_in[r] bit idx[o], o < n_out (bit gather).  Undoes the spatial point sort the
+ * host applies at upload: idx[o] = position of original point o in the sorted cloud. */
+int bff_permute_bits(const uint64_t *rows_in, int32_t n_rows, int64_t nw_in, const int32_t *idx,
+                     int64_t n_out, int64_t nw_out, uint64_t *rows_out, void *stream);
 
 /* a12: connected components of a symmetric bit adjacency (find_unconnected_subgraphs_tensor
  * P:250-274 computes the transitive closure by n rounds of clamp(R@A + A); for the symmetric

@@ -214,6 +214,61 @@ def test_merge_adjacency_and_components(lib, r, n):
     assert got == pref.connected_groups(merge.float())
 
 
+@pytest.mark.parametrize("thr", [0.2, 0.0, -1.0])
+def test_merge_adjacency_block_sparse_equals_dense(lib, thr):
+    """Row order + chunk skipping change nothing: adjacency (indexed by position in `order`) and the
+    Gram equal the dense all-words result, incl. thr < 0 where empty intersections DO count."""
+    rng = np.random.default_rng(17)
+    r, n = 300, 40_000                     # 625 words = 79 chunks of 8 words
+    d = np.zeros((r, n), bool)
+    for i in range(r):
+        c = int(rng.integers(0, 6)) * 6000 + int(rng.integers(0, 500))
+        d[i, c: c + int(rng.integers(50, 3000))] = True
+        d[i] &= rng.random(n) < 0.7
+    d[5] = False; d[77] = False
+    labels = rng.integers(0, 2, r)
+    rows = pack_np(d)
+    lid = torch.tensor(labels, dtype=torch.int32, device=DEV)
+    area, mean_word, cmask = lib.row_stats(rows)
+    assert np.array_equal(area.cpu().numpy(), d.sum(1))
+    occ = np.add.reduceat(np.pad(d, ((0, 0), (0, (-n) % 512))), np.arange(0, n, 512), axis=1) > 0
+    assert np.array_equal(unpack(cmask, occ.shape[1]), occ)
+    assert mean_word[5].item() == 0x7fffffff
+    order = torch.argsort((lid.long() << 32) | mean_word.long()).to(torch.int32)
+    dense_adj, dense_inter = lib.merge_adjacency(rows, area, lid, thr, want_inter=True)
+    sp_adj, sp_inter = lib.merge_adjacency(rows, area, lid, thr, order=order, chunk_mask=cmask, want_inter=True)
+    o = order.cpu().numpy()
+    exp_inter = d.astype(np.int32) @ d.astype(np.int32).T
+    assert np.array_equal(dense_inter.cpu().numpy(), exp_inter)
+    assert np.array_equal(sp_inter.cpu().numpy(), exp_inter)
+    iou = pref.pairwise_iou(torch.from_numpy(d))
+    merge = ((torch.from_numpy(labels)[:, None] == torch.from_numpy(labels)[None, :]) & (iou > thr)).numpy()
+    assert np.array_equal(unpack(dense_adj, r), merge)
+    assert np.array_equal(unpack(sp_adj, r), merge[o][:, o])
+
+
+def test_permute_bits(lib):
+    rng = np.random.default_rng(4)
+    n = 10_007
+    d = random_rows(rng, 5, n, 0.3)
+    perm = rng.permutation(n)                       # sorted position s holds original point perm[s]
+    unsort = np.empty(n, np.int32); unsort[perm] = np.arange(n, dtype=np.int32)
+    sorted_rows = pack_np(d[:, perm])
+    back = lib.permute_bits(sorted_rows, torch.from_numpy(unsort).to(DEV), n)
+    assert np.array_equal(unpack(back, n), d) and torch.equal(back, pack_np(d))
+
+
+def test_morton_order_is_a_permutation():
+    from beyond_fixed_forms_amd.scene import morton_order
+    rng = np.random.default_rng(0)
+    p = rng.uniform(-3, 3, (5000, 3)); p[7] = np.nan
+    o = morton_order(p)
+    assert sorted(o.tolist()) == list(range(5000))
+    q = p[o]
+    # neighbours along the curve are close in space (median step far below the box size)
+    assert np.nanmedian(np.linalg.norm(np.diff(q, axis=0), axis=1)) < 0.6
+
+
 def test_components_long_chain(lib):
     """A path graph of 3000 nodes (worst case for label propagation) + isolated nodes."""
     n = 3000
