@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 from beyond_fixed_forms_amd import _lib, distributed as bdist  # noqa: E402
 from beyond_fixed_forms_amd.config import Config  # noqa: E402
 from beyond_fixed_forms_amd.projection import run_projection  # noqa: E402
-from beyond_fixed_forms_amd.refinement import TextSimilarity, refine_class  # noqa: E402
+from beyond_fixed_forms_amd.refinement import TextSimilarity, prepare_stage1, refine_class  # noqa: E402
 from beyond_fixed_forms_amd.scene import prepare_scene  # noqa: E402
 from beyond_fixed_forms_amd.synthetic import SHAPES, make_scene, make_text_bank  # noqa: E402
 from beyond_fixed_forms_amd.timing import KernelTimers  # noqa: E402
@@ -118,6 +118,7 @@ def main():
     scene = make_scene(args.shape, seed=rank, device=dev, query=QUERY)
     cfg = Config.with_defaults(width_2d=scene.width, height_2d=scene.height)
     ds = prepare_scene(scene, cfg, device=dev)
+    stage1 = prepare_stage1(scene.stage1, dev)          # class-independent: uploaded with the scene
     bank, index = make_text_bank(768, seed=0)
     enc = bank_encoder(bank.float(), index)
     sim = TextSimilarity(enc, dev)
@@ -128,7 +129,7 @@ def main():
 
     def step(tm=None):
         res = run_projection(ds, cfg, timers=tm)
-        fin = refine_class([(scene.scene_id, scene.stage1, res)], cfg, QUERY, sim, dev, exchange_sims=exchange)
+        fin = refine_class([(scene.scene_id, stage1, res)], cfg, QUERY, sim, dev, exchange_sims=exchange)
         rows = fin[scene.scene_id].rows
         if rows is None:
             rows = torch.zeros((0, ds.nw), dtype=torch.int64, device=dev)

@@ -24,11 +24,12 @@ SIGNATURES = {
     "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P],
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
-    "bff_row_stats": [_P, _I, _L, _P, _P, _P, _P],
-    "bff_merge_adjacency": [_P, _I, _L, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "bff_row_stats": [_P, _I, _L, _P, _P, _P, _P, _P, _P],
+    "bff_merge_components": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "bff_merge_adjacency": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "bff_permute_bits": [_P, _I, _L, _P, _L, _L, _P, _P],
     "bff_components_round": [_P, _I, _P, _P, _P, _P],
-    "bff_or_reduce_groups": [_P, _L, _P, _P, _I, _P, _P],
+    "bff_or_reduce_groups": [_P, _L, _P, _P, _I, _I, _P, _P],
     "bff_group_conf_mean": [_P, _I, _P, _P, _I, _P, _P],
     "bff_apply_row_ops": [_P, _L, _P, _I, _P],
     "bff_and_rows": [_P, _I, _L, _P, _P],
@@ -139,17 +140,31 @@ def cross_popcount(a, b, ia=None, ib=None):
 
 
 def row_stats(rows):
-    """-> (area i32 [R], mean_word i32 [R], chunk_mask i64 [R][mw])."""
+    """-> (area i32 [R], mean_word i32 [R], chunk_mask i64 [R][mw], hist i32 [R][64], signature i64 [R])."""
     n = rows.shape[0]
     mw = load().bff_chunk_mask_words(rows.shape[1])
     area = torch.empty(n, dtype=i32, device=rows.device)
     mean_word = torch.empty(n, dtype=i32, device=rows.device)
     cmask = torch.empty((n, max(mw, 1)), dtype=i64, device=rows.device)
-    call("bff_row_stats", _ptr(rows, i64), n, rows.shape[1], _ptr(area), _ptr(mean_word), _ptr(cmask))
-    return area, mean_word, cmask
+    hist = torch.empty((n, 64), dtype=i32, device=rows.device)
+    sig = torch.empty(n, dtype=i64, device=rows.device)
+    call("bff_row_stats", _ptr(rows, i64), n, rows.shape[1], _ptr(area), _ptr(mean_word), _ptr(cmask), _ptr(hist),
+         _ptr(sig))
+    return area, mean_word, cmask, hist, sig
 
 
-def merge_adjacency(rows, area, label_id, iou_thres, order=None, chunk_mask=None, want_inter=False):
+def merge_components(rows, area, label_id, iou_thres, order, chunk_mask, hist):
+    """comp[i] = smallest row index of the component of row i in the merge graph (one pass, no adjacency)."""
+    n = rows.shape[0]
+    tmask = torch.empty(((n + 63) // 64, chunk_mask.shape[1]), dtype=i64, device=rows.device)
+    parent = torch.empty(n, dtype=i32, device=rows.device)
+    comp = torch.empty(n, dtype=i32, device=rows.device)
+    call("bff_merge_components", _ptr(rows, i64), n, rows.shape[1], _ptr(order, i32), _ptr(chunk_mask, i64),
+         _ptr(tmask), _ptr(hist, i32), _ptr(area, i32), _ptr(label_id, i32), float(iou_thres), _ptr(parent), _ptr(comp))
+    return comp
+
+
+def merge_adjacency(rows, area, label_id, iou_thres, order=None, chunk_mask=None, hist=None, want_inter=False):
     """Adjacency bit matrix indexed by position in `order` (identity when None)."""
     n = rows.shape[0]
     aw = (n + 63) // 64
@@ -159,7 +174,7 @@ def merge_adjacency(rows, area, label_id, iou_thres, order=None, chunk_mask=None
     if chunk_mask is not None:
         tmask = torch.empty((aw, chunk_mask.shape[1]), dtype=i64, device=rows.device)
     call("bff_merge_adjacency", _ptr(rows, i64), n, rows.shape[1], _ptr(order, i32), _ptr(chunk_mask, i64),
-         _ptr(tmask), _ptr(area, i32), _ptr(label_id, i32), float(iou_thres), _ptr(adj), _ptr(inter))
+         _ptr(tmask), _ptr(hist, i32), _ptr(area, i32), _ptr(label_id, i32), float(iou_thres), _ptr(adj), _ptr(inter))
     return (adj, inter) if want_inter else adj
 
 
@@ -186,10 +201,11 @@ def components(adj, max_rounds=10_000):
     raise RuntimeError("bff_components_round did not converge")
 
 
-def or_reduce_groups(rows, group_offs, members):
+def or_reduce_groups(rows, group_offs, members, max_group_size):
     k = group_offs.shape[0] - 1
     out = torch.empty((k, rows.shape[1]), dtype=i64, device=rows.device)
-    call("bff_or_reduce_groups", _ptr(rows, i64), rows.shape[1], _ptr(group_offs, i32), _ptr(members, i32), k, _ptr(out))
+    call("bff_or_reduce_groups", _ptr(rows, i64), rows.shape[1], _ptr(group_offs, i32), _ptr(members, i32), k,
+         int(max_group_size), _ptr(out))
     return out
 
 

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void popcount_rows_kernel(const uint64_t *__re
 __device__ __forceinline__ void tile_popcount(const uint64_t *__restrict__ a, const int32_t *__restrict__ ia,
                                               int na, int i0, const uint64_t *__restrict__ b,
                                               const int32_t *__restrict__ ib, int nb, int j0, int64_t nw,
+                                              int64_t k_begin, int64_t k_end,
                                               uint64_t (*sa)[kPitch], uint64_t (*sb)[kPitch], int acc[4][4])
 {
     const int tid = threadIdx.x;
@@ -55,7 +56,7 @@ __device__ __forceinline__ void tile_popcount(const uint64_t *__restrict__ a, co
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = 0;
-    for (int64_t k0 = 0; k0 < nw; k0 += kKW) {
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += kKW) {
         const bool kin = k0 + lk < nw;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -81,19 +82,25 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
                                                               const int32_t *__restrict__ ia, int na,
                                                               const uint64_t *__restrict__ b,
                                                               const int32_t *__restrict__ ib, int nb, int64_t nw,
-                                                              int32_t *__restrict__ inter)
+                                                              int64_t k_split, int32_t *__restrict__ inter)
 {
+    // blockIdx.z owns the word range [z*k_split, (z+1)*k_split): small row counts still fill the chip.
+    // Partial counts are combined with integer atomics (exact, order independent) into a zeroed matrix.
     __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
     int acc[4][4];
     const int i0 = blockIdx.y * kT, j0 = blockIdx.x * kT;
-    tile_popcount(a, ia, na, i0, b, ib, nb, j0, nw, sa, sb, acc);
+    const int64_t k_begin = (int64_t)blockIdx.z * k_split;
+    tile_popcount(a, ia, na, i0, b, ib, nb, j0, nw, k_begin, min(nw, k_begin + k_split), sa, sb, acc);
     const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int i = i0 + ti * 4 + r, j = j0 + tj * 4 + c;
-            if (i < na && j < nb) inter[(int64_t)i * nb + j] = acc[r][c];
+            if (i < na && j < nb) {
+                if (gridDim.z == 1) inter[(int64_t)i * nb + j] = acc[r][c];
+                else if (acc[r][c]) atomicAdd(inter + (int64_t)i * nb + j, acc[r][c]);
+            }
         }
 }
 
@@ -101,17 +108,22 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
 // Per row: popcount, occupancy mask over chunks of kCW words, and the mean word position of its set
 // bits (sort key that brings rows covering the same region of the -- spatially sorted -- cloud together).
 constexpr int kCW = 8;        // words per chunk (512 points)
+constexpr int kBins = 64;     // histogram bins per row (each ceil(nw/64) words wide)
 
 __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restrict__ rows, int64_t nw, int mw,
-                                                         int32_t *__restrict__ area, int32_t *__restrict__ mean_word,
-                                                         uint64_t *__restrict__ cmask)
+                                                         int bin_words, int32_t *__restrict__ area,
+                                                         int32_t *__restrict__ mean_word,
+                                                         uint64_t *__restrict__ cmask, uint32_t *__restrict__ hist,
+                                                         int64_t *__restrict__ signature)
 {
     extern __shared__ uint64_t s_cm[];                 // mw words
     __shared__ int part[4];
     __shared__ unsigned long long psum[4];
+    __shared__ uint32_t s_hist[kBins];
     const int r = blockIdx.x, tid = threadIdx.x;
     const uint64_t *row = rows + (int64_t)r * nw;
     for (int i = tid; i < mw; i += 256) s_cm[i] = 0;
+    if (tid < kBins) s_hist[tid] = 0;
     __syncthreads();
     int s = 0;
     unsigned long long ws = 0;
@@ -121,6 +133,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restri
             const int c = (int)(w / kCW);
             atomicOr((unsigned long long *)&s_cm[c >> 6], 1ull << (c & 63));
             const int pc = popc64(v);
+            atomicAdd(&s_hist[(int)(w / bin_words)], (uint32_t)pc);
             s += pc;
             ws += (unsigned long long)pc * (unsigned long long)w;
         }
@@ -130,6 +143,14 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restri
     if (lane_id() == 0) { part[tid >> 6] = s; psum[tid >> 6] = ws; }
     __syncthreads();
     for (int i = tid; i < mw; i += 256) cmask[(int64_t)r * mw + i] = s_cm[i];
+    const int a_all = part[0] + part[1] + part[2] + part[3];
+    if (tid < kBins) {
+        hist[(int64_t)r * kBins + tid] = s_hist[tid];
+        // bins holding >= 15 % of the row: rows of one object share this signature whatever the view, and
+        // stray "bleed" points never enter it.  Bin 0 is the most significant bit (sorts like a position).
+        const uint64_t heavy = __ballot((uint64_t)s_hist[tid] * 100 >= (uint64_t)a_all * 15 && a_all > 0);
+        if (tid == 0) signature[r] = a_all ? (int64_t)(__brevll(heavy) >> 1) : 0x7fffffffffffffffll;
+    }
     if (tid == 0) {
         const int a = part[0] + part[1] + part[2] + part[3];
         const unsigned long long t = psum[0] + psum[1] + psum[2] + psum[3];
@@ -163,6 +184,7 @@ constexpr int kMaxChunks = 4096;     // chunk list capacity (LDS): N <= 4096*512
 __global__ __launch_bounds__(256) void merge_adjacency_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
                                                                const int32_t *__restrict__ order,
                                                                const uint64_t *__restrict__ tmask, int mw,
+                                                               const uint32_t *__restrict__ hist,
                                                                const int32_t *__restrict__ area,
                                                                const int32_t *__restrict__ label_id, float thr,
                                                                uint64_t *__restrict__ adj, int aw,
@@ -180,6 +202,59 @@ __global__ __launch_bounds__(256) void merge_adjacency_kernel(const uint64_t *__
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
     const int n_chunks = (int)((nw + kCW - 1) / kCW);
 
+    // ---- can any pair of this tile be adjacent at all?  I(i,j) <= UB = sum over 64 bins of
+    // min(hist_i, hist_j); the float32 IoU expression below is monotone non-decreasing in I (a_i + a_j
+    // fixed, correctly rounded ops), so "label equal and iou(min(UB, a_i, a_j)) > thr" is a sound
+    // superset of the adjacent pairs.  A tile without candidates skips its word loop (all bits 0).
+    bool any_candidate = true;
+    if (hist) {
+        uint32_t (*ha)[kBins] = reinterpret_cast<uint32_t (*)[kBins]>(&sa[0][0]);    // [bin][row], 16 KB each
+        uint32_t (*hb)[kBins] = reinterpret_cast<uint32_t (*)[kBins]>(&sb[0][0]);
+        {
+            const int lane = tid & 63, wv = tid >> 6;
+            const int ra = i0 + lane, rb = j0 + lane;
+            const uint32_t *ga = ra < n ? hist + (int64_t)(order ? order[ra] : ra) * kBins : nullptr;
+            const uint32_t *gb = rb < n ? hist + (int64_t)(order ? order[rb] : rb) * kBins : nullptr;
+#pragma unroll
+            for (int q = 0; q < kBins / 4; ++q) {
+                const int b = wv * (kBins / 4) + q;
+                ha[b][lane] = ga ? ga[b] : 0;
+                hb[b][lane] = gb ? gb[b] : 0;
+            }
+        }
+        __syncthreads();
+        uint32_t ub[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ub[r][c] = 0;
+#pragma unroll 4
+        for (int b = 0; b < kBins; ++b) {
+            uint32_t av[4], bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { av[r] = ha[b][ti * 4 + r]; bv[r] = hb[b][tj * 4 + r]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ub[r][c] += min(av[r], bv[c]);
+        }
+        bool cand = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int si = i0 + ti * 4 + r, sj = j0 + tj * 4 + c;
+                if (si < n && sj < n) {
+                    const int i = order ? order[si] : si, j = order ? order[sj] : sj;
+                    const int ai = area[i], aj = area[j];
+                    const float fi = (float)min((int)ub[r][c], min(ai, aj));
+                    const float iou = __fdiv_rn(fi, (float)ai + (float)aj - fi);
+                    cand |= (label_id[i] == label_id[j]) && (iou > thr);
+                }
+            }
+        any_candidate = __syncthreads_or(cand);
+    }
+
     // ---- chunks to visit
     if (tid < kWave) {
         int base = 0;
@@ -194,7 +269,7 @@ __global__ __launch_bounds__(256) void merge_adjacency_kernel(const uint64_t *__
         if (tid == 0) s_cnt = base;
     }
     __syncthreads();
-    const int cnt = s_cnt;
+    const int cnt = any_candidate ? s_cnt : 0;
 
     int acc[4][4];
 #pragma unroll
@@ -271,6 +346,189 @@ __global__ __launch_bounds__(256) void merge_adjacency_kernel(const uint64_t *__
     }
 }
 
+// ---- components without an adjacency matrix: union-find in the tile epilogue -----------------------
+// parent[] is a disjoint-set forest over ROW indices (roots point to themselves, links go to the
+// smaller index).  Reads bypass L1 (agent-scope relaxed atomics) so every wave sees links made by
+// other CUs; a stale view can only make a tile do work it could have skipped, never change the result:
+// once two rows share a root they are connected for good, and links are made with compare-and-swap.
+__device__ __forceinline__ int uf_find(int32_t *parent, int x)
+{
+    int p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        x = p;
+        p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return x;
+}
+
+__device__ __forceinline__ void uf_union(int32_t *parent, int a, int b)
+{
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }            // a > b: hang the larger root under the smaller
+        int expected = a;
+        if (__hip_atomic_compare_exchange_strong(parent + a, &expected, b, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT))
+            return;
+    }
+}
+
+__global__ void uf_init_kernel(int32_t *parent, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) parent[i] = i;
+}
+
+__global__ void uf_flatten_kernel(int32_t *parent, int n, int32_t *comp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) comp[i] = uf_find(parent, i);                      // = smallest row index of the component
+}
+
+// Tile pairs are enumerated diagonal-first (|bi - bj| = 0, 1, 2, ...): with rows clustered by signature
+// the first tiles discover the large components, and later tiles find most of their possible edges
+// already inside one component and skip their word loop.
+__global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
+                                                                const int32_t *__restrict__ order,
+                                                                const uint64_t *__restrict__ tmask, int mw,
+                                                                const uint32_t *__restrict__ hist,
+                                                                const int32_t *__restrict__ area,
+                                                                const int32_t *__restrict__ label_id, float thr,
+                                                                int32_t *__restrict__ parent, int n_tiles)
+{
+    __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
+    __shared__ uint16_t clist[kMaxChunks];
+    __shared__ int s_cnt;
+    __shared__ int rowA[kT], rowB[kT], rootA[kT], rootB[kT];
+    int t = blockIdx.x, d = 0;
+    while (t >= n_tiles - d) { t -= n_tiles - d; ++d; }           // d = bj - bi
+    const int bi = t, bj = t + d;
+    const int i0 = bi * kT, j0 = bj * kT;
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int n_chunks = (int)((nw + kCW - 1) / kCW);
+
+    if (tid < kT) {
+        const int r = i0 + tid;
+        rowA[tid] = r < n ? (order ? order[r] : r) : -1;
+        rootA[tid] = rowA[tid] >= 0 ? uf_find(parent, rowA[tid]) : -1;
+    } else if (tid < 2 * kT) {
+        const int r = j0 + tid - kT;
+        rowB[tid - kT] = r < n ? (order ? order[r] : r) : -1;
+        rootB[tid - kT] = rowB[tid - kT] >= 0 ? uf_find(parent, rowB[tid - kT]) : -2;
+    }
+    // histogram bound (see merge_adjacency_kernel): possible edges only
+    uint32_t (*ha)[kBins] = reinterpret_cast<uint32_t (*)[kBins]>(&sa[0][0]);
+    uint32_t (*hb)[kBins] = reinterpret_cast<uint32_t (*)[kBins]>(&sb[0][0]);
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        const int ra = i0 + lane, rb = j0 + lane;
+        const uint32_t *ga = ra < n ? hist + (int64_t)(order ? order[ra] : ra) * kBins : nullptr;
+        const uint32_t *gb = rb < n ? hist + (int64_t)(order ? order[rb] : rb) * kBins : nullptr;
+#pragma unroll
+        for (int q = 0; q < kBins / 4; ++q) {
+            const int b = wv * (kBins / 4) + q;
+            ha[b][lane] = ga ? ga[b] : 0;
+            hb[b][lane] = gb ? gb[b] : 0;
+        }
+    }
+    __syncthreads();
+    uint32_t ub[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ub[r][c] = 0;
+#pragma unroll 4
+    for (int b = 0; b < kBins; ++b) {
+        uint32_t av[4], bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { av[r] = ha[b][ti * 4 + r]; bv[r] = hb[b][tj * 4 + r]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ub[r][c] += min(av[r], bv[c]);
+    }
+    unsigned cand = 0;                                             // bit 4r+c: pair still needs the exact test
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = rowA[ti * 4 + r], j = rowB[tj * 4 + c];
+            if (i >= 0 && j >= 0 && i != j && rootA[ti * 4 + r] != rootB[tj * 4 + c] && (d > 0 || ti * 4 + r < tj * 4 + c)) {
+                const int ai = area[i], aj = area[j];
+                const float fi = (float)min((int)ub[r][c], min(ai, aj));
+                const float iou = __fdiv_rn(fi, (float)ai + (float)aj - fi);
+                if ((label_id[i] == label_id[j]) && (iou > thr)) cand |= 1u << (4 * r + c);
+            }
+        }
+    const int any_candidate = __syncthreads_or(cand != 0);
+    if (!any_candidate) return;                                    // block-uniform
+
+    if (tid < kWave) {
+        int base = 0;
+        for (int m = 0; m < (n_chunks + 63) / 64; ++m) {
+            const uint64_t bits = tmask ? (tmask[(int64_t)bi * mw + m] & tmask[(int64_t)bj * mw + m]) : ~0ull;
+            const int c = m * 64 + tid;
+            const bool on = ((bits >> tid) & 1) && c < n_chunks;
+            const uint64_t bal = __ballot(on);
+            if (on) clist[base + __popcll(bal & ((1ull << tid) - 1))] = (uint16_t)c;
+            base += __popcll(bal);
+        }
+        if (tid == 0) s_cnt = base;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    int acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+    {
+        const int lk = tid & (kKW - 1), lr = tid >> 5;
+        const int slot = lk / kCW, cw = lk % kCW;
+        const uint64_t *pa[8];
+        const uint64_t *pb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ra = rowA[lr + 8 * q], rb = rowB[lr + 8 * q];
+            pa[q] = ra >= 0 ? rows + (int64_t)ra * nw : nullptr;
+            pb[q] = rb >= 0 ? rows + (int64_t)rb * nw : nullptr;
+        }
+        for (int g = 0; g < cnt; g += kKW / kCW) {
+            const int64_t w = (g + slot < cnt) ? (int64_t)clist[g + slot] * kCW + cw : nw;
+            const bool kin = w < nw;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                sa[lk][lr + 8 * q] = (kin && pa[q]) ? pa[q][w] : 0;
+                sb[lk][lr + 8 * q] = (kin && pb[q]) ? pb[q][w] : 0;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int kk = 0; kk < kKW; ++kk) {
+                uint64_t av[4], bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { av[r] = sa[kk][ti * 4 + r]; bv[r] = sb[kk][tj * 4 + r]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[r][c] += popc64(av[r] & bv[c]);
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (cand & (1u << (4 * r + c))) {
+                const int i = rowA[ti * 4 + r], j = rowB[tj * 4 + c];
+                const float fi = (float)acc[r][c];
+                const float iou = __fdiv_rn(fi, (float)area[i] + (float)area[j] - fi);   // P:149-166
+                if (iou > thr) uf_union(parent, i, j);                                   // labels already equal
+            }
+}
+
 // out bit o of row r = in bit idx[o] of row r  (bit gather; undoes the spatial point sort)
 __global__ void permute_bits_kernel(const uint64_t *__restrict__ in, int64_t nw_in, const int32_t *__restrict__ idx,
                                     int64_t n_out, int64_t nw_out, uint64_t *__restrict__ out)
@@ -286,33 +544,53 @@ __global__ void permute_bits_kernel(const uint64_t *__restrict__ in, int64_t nw_
 }
 
 // ---- group OR / confidence mean ---------------------------------------------------------------
+constexpr int kOrSplit = 32;      // members per block along z
+
 __global__ void or_reduce_groups_kernel(const uint64_t *__restrict__ rows, int64_t nw,
                                         const int32_t *__restrict__ offs, const int32_t *__restrict__ members,
                                         uint64_t *__restrict__ out)
 {
+    // blockIdx.z takes members [z*32, z*32+32) of group blockIdx.y; partial ORs meet in the zeroed output
     const int g = blockIdx.y;
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nw) return;
+    const int lo = offs[g] + blockIdx.z * kOrSplit, hi = min(offs[g + 1], lo + kOrSplit);
+    if (w >= nw || lo >= hi) return;
     uint64_t v = 0;
-    for (int m = offs[g]; m < offs[g + 1]; ++m) v |= rows[(int64_t)members[m] * nw + w];
-    out[(int64_t)g * nw + w] = v;
+#pragma unroll 8
+    for (int m = lo; m < hi; ++m) v |= rows[(int64_t)members[m] * nw + w];
+    if (gridDim.z == 1) out[(int64_t)g * nw + w] = v;
+    else if (v) atomicOr((unsigned long long *)(out + (int64_t)g * nw + w), (unsigned long long)v);
 }
 
 template <typename T>
-__global__ void group_conf_mean_kernel(const T *__restrict__ conf, const int32_t *__restrict__ offs,
-                                       const int32_t *__restrict__ members, int n_groups, T *__restrict__ mean)
+__global__ __launch_bounds__(64) void group_conf_mean_kernel(const T *__restrict__ conf,
+                                                             const int32_t *__restrict__ offs,
+                                                             const int32_t *__restrict__ members, int n_groups,
+                                                             T *__restrict__ mean)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_groups) return;
+    // one wave per group: all lanes gather 1024 confidences into LDS at once (the gathers are the slow
+    // part), then lane 0 runs the strictly sequential sum the reference defines (P:225)
+    __shared__ T stage[1024];
+    const int g = blockIdx.x;
     const int lo = offs[g], hi = offs[g + 1];
-    if constexpr (sizeof(T) == 2) {
-        __half s = __float2half_rn(0.0f);
-        for (int m = lo; m < hi; ++m) s = __hadd(s, conf[members[m]]);    // one f16 rounding per step
-        mean[g] = __float2half_rn(__fdiv_rn(__half2float(s), (float)(hi - lo)));
-    } else {
-        float s = 0.0f;
-        for (int m = lo; m < hi; ++m) s = __fadd_rn(s, conf[members[m]]);
-        mean[g] = __fdiv_rn(s, (float)(hi - lo));
+    T s;
+    if constexpr (sizeof(T) == 2) s = __float2half_rn(0.0f); else s = 0.0f;
+    for (int base = lo; base < hi; base += 1024) {
+        const int cnt = min(1024, hi - base);
+        for (int k = threadIdx.x; k < cnt; k += 64) stage[k] = conf[members[base + k]];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll 8
+            for (int k = 0; k < cnt; ++k) {
+                if constexpr (sizeof(T) == 2) s = __hadd(s, stage[k]);        // one f16 rounding per step
+                else s = __fadd_rn(s, stage[k]);
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if constexpr (sizeof(T) == 2) mean[g] = __float2half_rn(__fdiv_rn(__half2float(s), (float)(hi - lo)));
+        else mean[g] = __fdiv_rn(s, (float)(hi - lo));
     }
 }
 
@@ -415,28 +693,41 @@ extern "C" int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t 
     BFF_REQUIRE(na >= 0 && nb >= 0 && nw >= 0, "bff_cross_popcount: bad sizes");
     if (na == 0 || nb == 0) return BFF_OK;
     BFF_REQUIRE(a && b && inter, "bff_cross_popcount: null pointer");
-    dim3 grid((unsigned)ceil_div(nb, kT), (unsigned)ceil_div(na, kT));
-    cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, ia, na, b, ib, nb, nw, inter);
+    const int64_t tiles = ceil_div(nb, kT) * ceil_div(na, kT);
+    int64_t k_split = nw;                               // words per block along z
+    if (tiles < 512) {                                  // few tiles: split the words so >= ~512 blocks run
+        k_split = ceil_div(ceil_div(nw * tiles, 512), kKW) * kKW;
+        if (k_split < 2 * kKW) k_split = 2 * kKW;
+    }
+    const int64_t nz = ceil_div(nw, k_split);
+    if (nz > 1) {
+        hipError_t e = hipMemsetAsync(inter, 0, sizeof(int32_t) * (size_t)na * nb, as_stream(stream));
+        if (e != hipSuccess) return fail((int)e, "bff_cross_popcount: memset: %s", hipGetErrorString(e));
+    }
+    dim3 grid((unsigned)ceil_div(nb, kT), (unsigned)ceil_div(na, kT), (unsigned)nz);
+    cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, ia, na, b, ib, nb, nw, k_split, inter);
     return launched("bff_cross_popcount");
 }
 
 extern "C" int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *area, int32_t *mean_word,
-                             uint64_t *chunk_mask, void *stream)
+                             uint64_t *chunk_mask, uint32_t *hist, int64_t *signature, void *stream)
 {
     BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_row_stats: bad sizes");
     if (n_rows == 0) return BFF_OK;
-    BFF_REQUIRE(rows && area && mean_word && chunk_mask, "bff_row_stats: null pointer");
+    BFF_REQUIRE(rows && area && mean_word && chunk_mask && hist && signature, "bff_row_stats: null pointer");
     const int n_chunks = (int)ceil_div(nw, kCW);
     BFF_LIMIT(n_chunks <= kMaxChunks, "bff_row_stats: more than %d chunks (N > %d points)", kMaxChunks, kMaxChunks * kCW * 64);
     const int mw = (int)ceil_div(n_chunks, 64);
-    row_stats_kernel<<<n_rows, 256, mw * sizeof(uint64_t), as_stream(stream)>>>(rows, nw, mw, area, mean_word, chunk_mask);
+    row_stats_kernel<<<n_rows, 256, mw * sizeof(uint64_t), as_stream(stream)>>>(
+        rows, nw, mw, (int)ceil_div(nw > 0 ? nw : 1, kBins), area, mean_word, chunk_mask, hist, signature);
     return launched("bff_row_stats");
 }
 
 extern "C" int bff_chunk_mask_words(int64_t nw) { return (int)ceil_div(ceil_div(nw, kCW), 64); }
 
 extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
-                                   const uint64_t *chunk_mask, uint64_t *tile_mask, const int32_t *area,
+                                   const uint64_t *chunk_mask, uint64_t *tile_mask, const uint32_t *hist,
+                                   const int32_t *area,
                                    const int32_t *label_id, float iou_thres, uint64_t *adj, int32_t *inter,
                                    void *stream)
 {
@@ -454,8 +745,34 @@ extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t
     if (sparse) tile_masks_kernel<<<nt, 64, 0, as_stream(stream)>>>(chunk_mask, order, n_rows, mw, tile_mask);
     const int aw = nt;   // ceil(n_rows/64) words per adjacency row
     merge_adjacency_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, as_stream(stream)>>>(
-        rows, n_rows, nw, order, sparse ? tile_mask : nullptr, mw, area, label_id, iou_thres, adj, aw, inter, nt);
+        rows, n_rows, nw, order, sparse ? tile_mask : nullptr, mw, (sparse && !inter) ? hist : nullptr, area, label_id,
+        iou_thres, adj, aw, inter, nt);
     return launched("bff_merge_adjacency");
+}
+
+extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
+                                    const uint64_t *chunk_mask, uint64_t *tile_mask, const uint32_t *hist,
+                                    const int32_t *area, const int32_t *label_id, float iou_thres,
+                                    int32_t *parent, int32_t *comp, void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_merge_components: bad sizes");
+    if (n_rows == 0) return BFF_OK;
+    BFF_REQUIRE(rows && chunk_mask && tile_mask && hist && area && label_id && parent && comp && parent != comp,
+                "bff_merge_components: null pointer");
+    const int nt = (int)ceil_div(n_rows, kT);
+    BFF_LIMIT((int64_t)nt * (nt + 1) / 2 < (1ll << 31), "bff_merge_components: too many rows");
+    const int n_chunks = (int)ceil_div(nw, kCW);
+    BFF_LIMIT(n_chunks <= kMaxChunks, "bff_merge_components: more than %d chunks (N > %d points)", kMaxChunks, kMaxChunks * kCW * 64);
+    const int mw = (int)ceil_div(n_chunks, 64);
+    hipStream_t st = as_stream(stream);
+    uf_init_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows);
+    // an empty intersection gives IoU 0 (or NaN): such pairs can only be skipped when 0 > thr is false
+    const bool sparse = !(0.0f > iou_thres);
+    if (sparse) tile_masks_kernel<<<nt, 64, 0, st>>>(chunk_mask, order, n_rows, mw, tile_mask);
+    merge_components_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, st>>>(
+        rows, n_rows, nw, order, sparse ? tile_mask : nullptr, mw, hist, area, label_id, iou_thres, parent, nt);
+    uf_flatten_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows, comp);
+    return launched("bff_merge_components");
 }
 
 extern "C" int bff_permute_bits(const uint64_t *rows_in, int32_t n_rows, int64_t nw_in, const int32_t *idx,
@@ -470,12 +787,19 @@ extern "C" int bff_permute_bits(const uint64_t *rows_in, int32_t n_rows, int64_t
 }
 
 extern "C" int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int32_t *group_offs,
-                                    const int32_t *members, int32_t n_groups, uint64_t *out, void *stream)
+                                    const int32_t *members, int32_t n_groups, int32_t max_group_size,
+                                    uint64_t *out, void *stream)
 {
     BFF_REQUIRE(n_groups >= 0 && nw >= 0, "bff_or_reduce_groups: bad sizes");
     if (n_groups == 0 || nw == 0) return BFF_OK;
     BFF_REQUIRE(rows && group_offs && members && out, "bff_or_reduce_groups: null pointer");
-    dim3 grid((unsigned)ceil_div(nw, 256), (unsigned)n_groups);
+    // z covers the largest group in slices of kOrSplit members; max_group_size is a host-known bound
+    const int nz = (int)ceil_div(max_group_size > 0 ? max_group_size : 1, kOrSplit);
+    if (nz > 1) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t) * (size_t)n_groups * nw, as_stream(stream));
+        if (e != hipSuccess) return fail((int)e, "bff_or_reduce_groups: memset: %s", hipGetErrorString(e));
+    }
+    dim3 grid((unsigned)ceil_div(nw, 256), (unsigned)n_groups, (unsigned)nz);
     or_reduce_groups_kernel<<<grid, 256, 0, as_stream(stream)>>>(rows, nw, group_offs, members, out);
     return launched("bff_or_reduce_groups");
 }
@@ -486,7 +810,7 @@ extern "C" int bff_group_conf_mean(const void *conf, int32_t dtype, const int32_
     BFF_REQUIRE(n_groups >= 0 && (dtype == 0 || dtype == 1), "bff_group_conf_mean: bad arguments");
     if (n_groups == 0) return BFF_OK;
     BFF_REQUIRE(conf && group_offs && members && mean, "bff_group_conf_mean: null pointer");
-    const unsigned grid = (unsigned)ceil_div(n_groups, 64);
+    const unsigned grid = (unsigned)n_groups;
     if (dtype == 1)
         group_conf_mean_kernel<__half><<<grid, 64, 0, as_stream(stream)>>>((const __half *)conf, group_offs, members,
                                                                            n_groups, (__half *)mean);

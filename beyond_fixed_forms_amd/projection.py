@@ -54,23 +54,26 @@ def _empty(ds: DeviceScene, debug) -> Stage2Result:
 
 
 def groups_from_labels(comp: np.ndarray, has_self_loop: np.ndarray, min_members: int = 0):
-    """Component ids (any integer naming the component of node i) -> the list
-    find_unconnected_subgraphs_tensor returns (P:262-274), already filtered by
-    len >= min_members (P:203): components in order of their smallest member, members ascending; a
-    node whose adjacency row is empty (no self loop: empty mask, IoU NaN) yields an empty list."""
+    """Component ids (any integer naming the connected component of node i) -> the list
+    find_unconnected_subgraphs_tensor returns (P:262-274), already filtered by len >= min_members
+    (P:203): components in order of their smallest member, members ascending.  A node with no edge at
+    all -- a singleton component whose self-IoU is NaN (empty mask) or not above the threshold --
+    yields an empty list; a node without a self loop that has neighbours (possible only for
+    iou_thres < 0) is a normal member, since the closure reaches it back through a neighbour."""
     n = comp.shape[0]
-    idx = np.flatnonzero(has_self_loop)
-    out = []                                     # (first index, members)
-    if idx.size:
-        order = idx[np.argsort(comp[idx], kind="stable")]       # grouped by component, members ascending
-        cs = comp[order]
-        cut = np.flatnonzero(np.diff(cs)) + 1
-        starts = np.concatenate([[0], cut])
-        ends = np.concatenate([cut, [order.size]])
-        big = np.flatnonzero(ends - starts >= max(min_members, 1))
-        out = [(int(order[starts[g]]), order[starts[g]:ends[g]].tolist()) for g in big]
-    if min_members <= 0:                         # only then do the empty components survive the filter
-        out += [(int(i), []) for i in np.flatnonzero(~has_self_loop)]
+    if n == 0:
+        return []
+    order = np.argsort(comp, kind="stable")                    # grouped by component, members ascending
+    cs = comp[order]
+    cut = np.flatnonzero(np.diff(cs)) + 1
+    starts = np.concatenate([[0], cut])
+    ends = np.concatenate([cut, [n]])
+    size = ends - starts
+    first = order[starts]
+    void = (size == 1) & ~has_self_loop[first]                  # isolated node without a self loop -> []
+    eff = np.where(void, 0, size)
+    keep = np.flatnonzero(eff >= min_members)
+    out = [(int(first[g]), [] if void[g] else order[starts[g]:ends[g]].tolist()) for g in keep]
     out.sort(key=lambda kv: kv[0])
     return [m for _, m in out]
 
@@ -124,17 +127,16 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -
     if ds.n_rows == 0:                                                              # P:465-478
         return _empty(ds, dbg)
 
-    # a9-a12: IoU / label adjacency and its connected components (P:100-146, 250-274).  Rows are tiled in
-    # the order (label, mean position of the row's bits) so that a tile's rows occupy few chunks.
+    # a9-a12: components of the IoU / label merge graph (P:100-146, 250-274) in one pass.  Rows are tiled
+    # in the order (label, heavy-bin signature) so that a tile's rows occupy few chunks.
     with span(timers, "row_stats"):
-        area, mean_word, cmask = _lib.row_stats(rows)
-        order = torch.argsort((ds.label_id.to(torch.int64) << 32) | mean_word.to(torch.int64)).to(torch.int32)
-    with span(timers, "merge_adjacency"):
-        adj = _lib.merge_adjacency(rows, area, ds.label_id, cfg.iou_thres, order=order, chunk_mask=cmask)
-    with span(timers, "components"):
-        label_pos = _lib.components(adj)                     # component id per position in `order`
-        comp = torch.empty_like(label_pos)
-        comp[order.long()] = label_pos
+        area, _mean_word, cmask, hist, sig = _lib.row_stats(rows)
+        order = torch.argsort(sig, stable=True)
+        if len(set(ds.labels)) > 1:               # several label strings: cluster by label first
+            order = order[torch.argsort(ds.label_id[order], stable=True)]
+        order = order.to(torch.int32)
+    with span(timers, "merge_components"):
+        comp = _lib.merge_components(rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist)
         comp_h, area_h = comp.cpu().numpy(), area.cpu().numpy()
     self_loop = (area_h > 0) & bool(np.float32(1.0) > np.float32(cfg.iou_thres))
     groups = groups_from_labels(comp_h, self_loop, cfg.min_aggragated_masks)        # P:203
@@ -148,7 +150,7 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -
     np.cumsum([len(g) for g in merged], out=offs[1:])
     members = np.concatenate([np.asarray(g, dtype=np.int32) for g in merged])
     offs_d, members_d = torch.from_numpy(offs).to(dev), torch.from_numpy(members).to(dev)
-    agg = _lib.or_reduce_groups(rows, offs_d, members_d)
+    agg = _lib.or_reduce_groups(rows, offs_d, members_d, max(len(g) for g in merged))
     conf = _lib.group_conf_mean(ds.conf, offs_d, members_d)
     agg_labels = [ds.labels[g[0]] for g in merged]
     if not debug_out:

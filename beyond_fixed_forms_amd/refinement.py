@@ -71,16 +71,34 @@ def _stage2_rows(stage2, n_points, device):
     return _lib.pack_rows(ins.contiguous()), conf.cpu()
 
 
-def _stage1_rows(stage1, device):
-    """Open3DIS stage-1 dict -> (bit rows [S1][nw], n_points, label strings).  R:186-193."""
+@dataclasses.dataclass
+class DeviceStage1:
+    """Open3DIS stage-1 result of one scene with its RLE run tables resident in HBM.  Stage-1 masks do
+    not depend on the query class, so a scene's tables are uploaded once and decoded on the device
+    (bff_rle_to_rows) for every class."""
+    n_points: int
+    run_start: torch.Tensor
+    run_end: torch.Tensor
+    row_run_offs: torch.Tensor
+    labels: List[str]
+
+
+def prepare_stage1(stage1: dict, device="cuda") -> DeviceStage1:
+    """R:186-193: RLE "ins" -> run tables, class indices -> label strings."""
     rles = stage1["ins"]
     n_points = int(rles[0]["length"])
     if any(int(r["length"]) != n_points for r in rles):
         raise ValueError("stage-1 masks of different lengths")
     rs, re, offs = runs_from_rles(rles, "stage-1")
     t = lambda a: torch.from_numpy(a).to(device)
-    rows = _lib.rle_to_rows(t(rs), t(re), t(offs), n_points)
-    return rows, n_points, [idx_to_label(int(i)) for i in stage1["final_class"]]
+    return DeviceStage1(n_points, t(rs), t(re), t(offs), [idx_to_label(int(i)) for i in stage1["final_class"]])
+
+
+def _stage1_rows(stage1, device):
+    """stage-1 dict or DeviceStage1 -> (fresh bit rows [S1][nw], n_points, label strings)."""
+    st = stage1 if isinstance(stage1, DeviceStage1) else prepare_stage1(stage1, device)
+    rows = _lib.rle_to_rows(st.run_start, st.run_end, st.row_run_offs, st.n_points)
+    return rows, st.n_points, st.labels
 
 
 def _iou(inter: torch.Tensor, area_a: torch.Tensor, area_b: torch.Tensor) -> torch.Tensor:
@@ -152,7 +170,7 @@ def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: Text
         offs = np.zeros(len(parts) + 1, dtype=np.int32)
         np.cumsum([len(p) for p in parts], out=offs[1:])
         s2 = _lib.or_reduce_groups(s2, torch.from_numpy(offs).to(device),
-                                   i32([p for part in parts for p in part]))
+                                   i32([p for part in parts for p in part]), max(len(p) for p in parts))
 
     area1 = _lib.popcount_rows(s1).cpu()                                            # stage-1 rows may have grown
     area2 = _lib.popcount_rows(s2).cpu()
@@ -230,7 +248,7 @@ def refine_class(scenes, cfg, text_prompt: str, sim: TextSimilarity, device="cud
                  return_debug: bool = False):
     """Reference R:135-428 on in-memory inputs.
 
-    scenes: list of (scene_id, stage1_dict_or_None, stage2) in the sorted order of the stage-2
+    scenes: list of (scene_id, stage1 dict / DeviceStage1 / None, stage2) in the sorted order of the stage-2
     directory listing (R:154); stage2 is a Stage2Result, the reference's saved dict, or None for a
     missing file (R:175-178: such scenes are skipped in pass 1).  `exchange_sims` lets the
     multi-GPU driver widen the similarity set of pass 1 to all ranks (the one cross-scene

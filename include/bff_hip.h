@@ -111,9 +111,12 @@ int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t na,
 /* Per-row statistics that make the Gram block-sparse: area[r] = popcount(row r); mean_word[r] = mean word
  * index of its set bits (INT32_MAX for an empty row; a sort key that groups rows covering the same part of
  * the cloud when the points are spatially sorted); chunk_mask[r] = occupancy bits over chunks of 8 words
- * (512 points), bff_chunk_mask_words(nw) uint64 words per row. */
+ * (512 points), bff_chunk_mask_words(nw) uint64 words per row; hist[r] = uint32 [64] histogram of the
+ * row's set bits over 64 equal word ranges (bin width ceil(nw/64) words); signature[r] = int64 key whose bit
+ * (62 - b) says "bin b holds >= 15 % of the row" (INT64_MAX for an empty row): rows showing the same object
+ * get the same key, so sorting by it clusters them into the same 64-row tiles. */
 int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *area, int32_t *mean_word,
-                  uint64_t *chunk_mask, void *stream);
+                  uint64_t *chunk_mask, uint32_t *hist, int64_t *signature, void *stream);
 int bff_chunk_mask_words(int64_t nw);
 
 /* a9-a11: merge adjacency of `aggregate` P:100-146.  For every pair (i, j):
@@ -127,11 +130,32 @@ int bff_chunk_mask_words(int64_t nw);
  * chunk_mask (from bff_row_stats) + tile_mask (scratch, uint64 [ceil(n_rows/64)][bff_chunk_mask_words(nw)])
  * enable chunk skipping: a 64x64 tile pair only visits chunks both tiles occupy (exact: skipped words
  * contribute 0 to every intersection); both NULL = visit every word.
+ * hist (from bff_row_stats, may be NULL; used only together with chunk_mask and when inter == NULL): a tile
+ * pair first bounds every intersection by UB = sum_bins min(hist_i, hist_j) >= I and evaluates the same
+ * float32 IoU test on min(UB, area_i, area_j) (the test is monotone in I); tiles without a possible edge
+ * skip their word loop.  Sound: the adjacency is unchanged.
  * inter (optional, may be NULL): int32 [n_rows][n_rows] Gram matrix in ROW index space, for tests. */
 int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
-                        const uint64_t *chunk_mask, uint64_t *tile_mask, const int32_t *area,
+                        const uint64_t *chunk_mask, uint64_t *tile_mask, const uint32_t *hist,
+                        const int32_t *area,
                         const int32_t *label_id, float iou_thres,
                         uint64_t *adj, int32_t *inter, void *stream);
+
+/* a9-a12 in one pass, the production path: connected components of the merge graph of `aggregate`
+ * (same adjacency definition as bff_merge_adjacency) WITHOUT materialising the adjacency matrix and
+ * without the transitive-closure matmuls of find_unconnected_subgraphs_tensor P:250-274.  64x64 tile pairs
+ * are visited diagonal-first in `order`; a pair is examined only if the histogram bound allows an edge AND
+ * its two rows are not yet in one component; edges found are merged into a disjoint-set forest
+ * (`parent`, int32 [n_rows] scratch) with compare-and-swap.  Exact: a pair is skipped only when it cannot
+ * be an edge or when adding the edge could not change the components.
+ * comp (int32 [n_rows], out): comp[i] = smallest row index of i's component.  Rows with an empty
+ * adjacency row (area 0, or thr >= 1) form singleton components here; the host turns them into the
+ * reference's empty lists (it knows area and thr).  All other arguments as for bff_merge_adjacency;
+ * chunk_mask, tile_mask and hist are required. */
+int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
+                         const uint64_t *chunk_mask, uint64_t *tile_mask, const uint32_t *hist,
+                         const int32_t *area, const int32_t *label_id, float iou_thres,
+                         int32_t *parent, int32_t *comp, void *stream);
 
 /* rows_out[r] bit o = rows_in[r] bit idx[o], o < n_out (bit gather).  Undoes the spatial point sort the
  * host applies at upload: idx[o] = position of original point o in the sorted cloud. */
@@ -149,9 +173,10 @@ int bff_components_round(const uint64_t *adj, int32_t n_nodes, const int32_t *la
                          int32_t *changed, void *stream);
 
 /* a13: out[g] = OR of rows[members[group_offs[g] .. group_offs[g+1])]      (merge_masks P:219-224;
- * also the `.any(dim=0)` merge of R:269). */
+ * also the `.any(dim=0)` merge of R:269).  max_group_size >= the largest group (host knows the groups);
+ * it only sizes the launch. */
 int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int32_t *group_offs, const int32_t *members,
-                         int32_t n_groups, uint64_t *out, void *stream);
+                         int32_t n_groups, int32_t max_group_size, uint64_t *out, void *stream);
 
 /* a13: mean[g] = (((c[m0] + c[m1]) + c[m2]) ...) / len, every step rounded to the confidence dtype
  * (P:225: python `sum(conf) / len(conf)` over 0-dim tensors).  dtype: 0 = float32, 1 = float16. */

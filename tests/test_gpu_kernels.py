@@ -210,7 +210,7 @@ def test_merge_adjacency_and_components(lib, r, n):
     assert np.array_equal(unpack(adj, r), merge.numpy())
     from beyond_fixed_forms_amd.projection import groups_from_labels
     lab = lib.components(adj).cpu().numpy()
-    got = groups_from_labels(lab, d.sum(1) > 0)
+    got = groups_from_labels(lab, np.diag(merge.numpy()))
     assert got == pref.connected_groups(merge.float())
 
 
@@ -229,7 +229,10 @@ def test_merge_adjacency_block_sparse_equals_dense(lib, thr):
     labels = rng.integers(0, 2, r)
     rows = pack_np(d)
     lid = torch.tensor(labels, dtype=torch.int32, device=DEV)
-    area, mean_word, cmask = lib.row_stats(rows)
+    area, mean_word, cmask, hist, sig = lib.row_stats(rows)
+    bw = -(-((n + 63) // 64) // 64)
+    exp_hist = np.add.reduceat(np.pad(d, ((0, 0), (0, 64 * 64 * bw - n))), np.arange(0, 64 * 64 * bw, 64 * bw), axis=1)
+    assert np.array_equal(hist.cpu().numpy(), exp_hist)
     assert np.array_equal(area.cpu().numpy(), d.sum(1))
     occ = np.add.reduceat(np.pad(d, ((0, 0), (0, (-n) % 512))), np.arange(0, n, 512), axis=1) > 0
     assert np.array_equal(unpack(cmask, occ.shape[1]), occ)
@@ -245,6 +248,17 @@ def test_merge_adjacency_block_sparse_equals_dense(lib, thr):
     merge = ((torch.from_numpy(labels)[:, None] == torch.from_numpy(labels)[None, :]) & (iou > thr)).numpy()
     assert np.array_equal(unpack(dense_adj, r), merge)
     assert np.array_equal(unpack(sp_adj, r), merge[o][:, o])
+    # with the histogram bound (production path: no Gram output) the adjacency is still identical
+    hb_adj = lib.merge_adjacency(rows, area, lid, thr, order=order, chunk_mask=cmask, hist=hist)
+    assert torch.equal(hb_adj, sp_adj)
+    # production path: components by on-device union-find, no adjacency matrix
+    from beyond_fixed_forms_amd.projection import groups_from_labels
+    exp_groups = pref.connected_groups(torch.from_numpy(merge).float())
+    self_loop = np.diag(merge)
+    for ordr in (order, torch.argsort(sig, stable=True).to(torch.int32),
+                 torch.from_numpy(rng.permutation(r).astype(np.int32)).to(DEV)):
+        comp = lib.merge_components(rows, area, lid, thr, ordr, cmask, hist).cpu().numpy()
+        assert groups_from_labels(comp, self_loop) == exp_groups
 
 
 def test_permute_bits(lib):
@@ -288,10 +302,13 @@ def test_or_reduce_and_conf_mean(lib, dtype):
     rng = np.random.default_rng(5)
     r, n = 40, 777
     d = random_rows(rng, r, n, 0.05)
-    groups = [[0, 5, 7], [1], [2, 3, 4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23], [39, 38]]
+    r, n = 1400, 777
+    d = random_rows(rng, r, n, 0.002)
+    groups = [[0, 5, 7], [1], [2, 3, 4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23], [39, 38],
+              list(range(40, 1400))[::-1]]          # > 1024 members: several LDS stages, several z slices
     offs = torch.tensor(np.cumsum([0] + [len(g) for g in groups]), dtype=torch.int32, device=DEV)
     mem = torch.tensor([i for g in groups for i in g], dtype=torch.int32, device=DEV)
-    out = lib.or_reduce_groups(pack_np(d), offs, mem)
+    out = lib.or_reduce_groups(pack_np(d), offs, mem, max(len(g) for g in groups))
     assert np.array_equal(unpack(out, n), np.stack([d[g].any(0) for g in groups]))
     conf = torch.from_numpy(rng.uniform(0.2, 0.5, r)).to(dtype)
     got = lib.group_conf_mean(conf.to(DEV), offs, mem).cpu()

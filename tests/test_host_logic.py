@@ -86,6 +86,11 @@ def test_groups_from_labels_matches_closure_components():
             for i in comp:
                 label[i] = comp[0]
         assert groups_from_labels(label.astype(np.int32), alive) == exp
+        assert groups_from_labels(label.astype(np.int32), alive, 2) == [g for g in exp if len(g) >= 2]
+    # a node without a self loop that has a neighbour is a normal member (iou_thres < 0 with an empty mask)
+    a = np.array([[1, 1, 0], [1, 0, 0], [0, 0, 0]], bool)
+    assert pref.connected_groups(torch.from_numpy(a).float()) == [[0, 1], []]
+    assert groups_from_labels(np.array([0, 0, 2]), np.array([True, False, False])) == [[0, 1], []]
 
 
 def test_threshold_from_lattice_equals_torch_unique():
