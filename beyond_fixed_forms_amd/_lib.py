@@ -25,7 +25,7 @@ SIGNATURES = {
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
     "bff_row_stats": [_P, _I, _L, _P, _P, _P, _P, _P, _P],
-    "bff_merge_components": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "bff_merge_components": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P],
     "bff_merge_adjacency": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "bff_permute_bits": [_P, _I, _L, _P, _L, _L, _P, _P],
     "bff_components_round": [_P, _I, _P, _P, _P, _P],
@@ -37,8 +37,9 @@ SIGNATURES = {
     "bff_unpack_rows": [_P, _I, _L, _L, _P, _P],
     "bff_pack_rows": [_P, _I, _L, _L, _P, _P],
     "bff_rle_to_rows": [_P, _P, _P, _I, _L, _L, _P, _P],
-    "bff_count_lattice": [_P, _P, _L, _I, _I, _P, _P],
-    "bff_ratio_keep": [_P, _P, _L, _F, _I, _L, _P, _P],
+    "bff_ratio_keep": [_P, _P, _L, _F, _P, _I, _L, _P, _P],
+    "bff_point_values": [_P, _P, _L, _P, _P],
+    "bff_select_unique_rank": [_P, _L, _D, _P, _P, _P, _P],
     "bff_cosine_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
 }
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
@@ -153,14 +154,19 @@ def row_stats(rows):
     return area, mean_word, cmask, hist, sig
 
 
-def merge_components(rows, area, label_id, iou_thres, order, chunk_mask, hist):
+def merge_components(rows, area, label_id, iou_thres, order, chunk_mask, hist, diag=None, parent=None):
     """comp[i] = smallest row index of the component of row i in the merge graph (one pass, no adjacency)."""
     n = rows.shape[0]
     tmask = torch.empty(((n + 63) // 64, chunk_mask.shape[1]), dtype=i64, device=rows.device)
-    parent = torch.empty(n, dtype=i32, device=rows.device)
+    init = parent is None
+    if init:
+        parent = torch.empty(n, dtype=i32, device=rows.device)
     comp = torch.empty(n, dtype=i32, device=rows.device)
+    nt = (n + 63) // 64
+    hist_sorted = torch.empty(64 * 64 * nt + 65 * nt, dtype=i32, device=rows.device)      # scratch, see bff_hip.h
     call("bff_merge_components", _ptr(rows, i64), n, rows.shape[1], _ptr(order, i32), _ptr(chunk_mask, i64),
-         _ptr(tmask), _ptr(hist, i32), _ptr(area, i32), _ptr(label_id, i32), float(iou_thres), _ptr(parent), _ptr(comp))
+         _ptr(tmask), _ptr(hist, i32), _ptr(hist_sorted), _ptr(area, i32), _ptr(label_id, i32), float(iou_thres),
+         _ptr(parent), int(init), _ptr(comp), _ptr(diag, i32))
     return comp
 
 
@@ -257,17 +263,38 @@ def rle_to_rows(run_start, run_end, row_run_offs, n_points):
     return rows
 
 
-def count_lattice(masked, viewed, m_max, v_max):
-    presence = torch.zeros((m_max + 1) * (v_max + 1), dtype=u8, device=masked.device)
-    call("bff_count_lattice", _ptr(masked, i32), _ptr(viewed, i32), masked.shape[0], m_max, v_max, _ptr(presence))
-    return presence
+def point_threshold(masked, viewed, fraction):
+    """Device-resident threshold unique()[floor(fraction * n_unique)] of masked/(viewed+1) (or of masked when
+    viewed is None), P:513-518 / 571-576.  Returns (thr f32[1], n_unique i32[1]) on the device."""
+    n = masked.shape[0]
+    dev = masked.device
+    vals = torch.empty(n, dtype=f32, device=dev)
+    call("bff_point_values", _ptr(masked, i32), _ptr(viewed, i32), n, _ptr(vals))
+    vals = torch.sort(vals).values                      # library sort (plumbing), N floats
+    scratch = torch.empty(max(1, (n + 1023) // 1024), dtype=i32, device=dev)
+    thr = torch.empty(1, dtype=f32, device=dev)
+    n_unique = torch.empty(1, dtype=i32, device=dev)
+    call("bff_select_unique_rank", _ptr(vals), n, float(fraction), _ptr(scratch), _ptr(thr), _ptr(n_unique))
+    return thr, n_unique
+
+
+def fetch(*tensors):
+    """Device tensors -> numpy arrays with ONE stream synchronisation (pinned staging, async copies)."""
+    host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+    for h, t in zip(host, tensors):
+        h.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return [h.numpy() for h in host]
 
 
 def ratio_keep(masked, viewed, thr, use_thr):
+    """thr: python float, or a float32 device tensor of one element (threshold stays on the device)."""
     n = masked.shape[0]
     nw = (n + 63) // 64
     keep = torch.empty(nw, dtype=i64, device=masked.device)
-    call("bff_ratio_keep", _ptr(masked, i32), _ptr(viewed, i32), n, float(thr), int(bool(use_thr)), nw, _ptr(keep))
+    thr_dev = thr if torch.is_tensor(thr) else None
+    call("bff_ratio_keep", _ptr(masked, i32), _ptr(viewed, i32), n, 0.0 if thr_dev is not None else float(thr),
+         _ptr(thr_dev, f32), int(bool(use_thr)), nw, _ptr(keep))
     return keep
 
 

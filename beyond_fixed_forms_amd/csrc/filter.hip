@@ -6,19 +6,95 @@
 
 namespace bff {
 
-__global__ void count_lattice_kernel(const int32_t *__restrict__ masked, const int32_t *__restrict__ viewed,
-                                     int64_t n, int v_max, uint8_t *__restrict__ presence)
+// vals[i] = float32 filter statistic of point i: masked/(viewed+1) (P:571) or masked (P:513)
+__global__ void point_values_kernel(const int32_t *__restrict__ masked, const int32_t *__restrict__ viewed, int64_t n,
+                                    float *__restrict__ vals)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int64_t cell = (int64_t)masked[i] * (v_max + 1) + (viewed ? viewed[i] : 0);
-    presence[cell] = 1;         // racing writers all store the same byte
+    const float m = (float)masked[i];
+    vals[i] = viewed ? __fdiv_rn(m, __fadd_rn((float)viewed[i], 1.0f)) : m;
+}
+
+// sorted ascending -> thr = (distinct values)[floor(frac * n_distinct)], exactly the reference's
+// `x.unique()[math.floor(frac * x.unique().shape[0])]` (P:516-518, 574-576; frac * n is a float64 product).
+// Pass 1: every block counts the positions that start a run of equal values.  Pass 2 (one block): prefix
+// over the block counts gives n_distinct and the block holding the wanted rank; that block's slice is
+// scanned by one wave.
+constexpr int kSelBlock = 1024;      // elements per block in pass 1
+
+__global__ __launch_bounds__(256) void distinct_count_kernel(const float *__restrict__ sorted, int64_t n,
+                                                              int32_t *__restrict__ block_count)
+{
+    __shared__ int part[4];
+    const int64_t base = (int64_t)blockIdx.x * kSelBlock;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kSelBlock / 256; ++k) {
+        const int64_t i = base + threadIdx.x + k * 256;
+        if (i < n) c += (i == 0) || (sorted[i] != sorted[i - 1]);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if (lane_id() == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(1024) void distinct_select_kernel(const float *__restrict__ sorted, int64_t n,
+                                                                const int32_t *__restrict__ block_count, int n_blocks,
+                                                                double frac, float *__restrict__ thr,
+                                                                int32_t *__restrict__ n_unique)
+{
+    __shared__ int wsum[16];
+    __shared__ int s_total, s_block, s_before;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n_blocks + 1023) / 1024;
+    const int lo = tid * per, hi = min(n_blocks, lo + per);
+    int mine = 0;
+    for (int b = lo; b < hi; ++b) mine += block_count[b];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+    if (lane == 63) wsum[wave] = incl;
+    if (tid == 0) s_block = -1;
+    __syncthreads();
+    int before = incl - mine;
+    for (int q = 0; q < wave; ++q) before += wsum[q];
+    if (tid == 1023) s_total = before + mine;
+    __syncthreads();
+    const int total = s_total;
+    const long long rank = (long long)floor(frac * (double)total);
+    if (rank >= 0 && rank < total && rank >= before && rank < before + mine) {
+        int acc = before;
+        for (int b = lo; b < hi; ++b) {
+            if (rank < acc + block_count[b]) { s_block = b; s_before = acc; break; }
+            acc += block_count[b];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { *n_unique = total; if (s_block < 0) *thr = __builtin_nanf(""); }
+    if (s_block < 0 || wave != 0) return;
+    // one wave walks the 1024 elements of the chosen block, 64 at a time
+    const int64_t base = (int64_t)s_block * kSelBlock;
+    int seen = s_before;
+    for (int k = 0; k < kSelBlock / 64; ++k) {
+        const int64_t i = base + k * 64 + lane;
+        const bool start = i < n && ((i == 0) || (sorted[i] != sorted[i - 1]));
+        const uint64_t bal = __ballot(start);
+        const int my = seen + __popcll(bal & ((1ull << lane) - 1));
+        if (start && my == (int)rank) *thr = sorted[i];
+        seen += __popcll(bal);
+        if (seen > rank) break;
+    }
 }
 
 __global__ void ratio_keep_kernel(const int32_t *__restrict__ masked, const int32_t *__restrict__ viewed, int64_t n,
-                                  float thr, int use_thr, int64_t nw, uint64_t *__restrict__ keep)
+                                  float thr_imm, const float *__restrict__ thr_dev, int use_thr, int64_t nw,
+                                  uint64_t *__restrict__ keep)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float thr = thr_dev ? *thr_dev : thr_imm;
     bool k = false;
     if (i < n) {
         const int m = masked[i];
@@ -36,23 +112,31 @@ __global__ void ratio_keep_kernel(const int32_t *__restrict__ masked, const int3
 
 using namespace bff;
 
-extern "C" int bff_count_lattice(const int32_t *masked, const int32_t *viewed, int64_t n_points, int32_t m_max,
-                                 int32_t v_max, uint8_t *presence, void *stream)
+extern "C" int bff_point_values(const int32_t *masked, const int32_t *viewed, int64_t n_points, float *vals, void *stream)
 {
-    BFF_REQUIRE(n_points >= 0 && m_max >= 0 && v_max >= 0, "bff_count_lattice: bad sizes");
+    BFF_REQUIRE(n_points >= 0, "bff_point_values: bad size");
     if (n_points == 0) return BFF_OK;
-    BFF_REQUIRE(masked && presence, "bff_count_lattice: null pointer");
-    (void)m_max;   // bounds are the caller's contract: masked <= m_max, viewed <= v_max
-    count_lattice_kernel<<<(unsigned)ceil_div(n_points, 256), 256, 0, as_stream(stream)>>>(masked, viewed, n_points, v_max, presence);
-    return launched("bff_count_lattice");
+    BFF_REQUIRE(masked && vals, "bff_point_values: null pointer");
+    point_values_kernel<<<(unsigned)ceil_div(n_points, 256), 256, 0, as_stream(stream)>>>(masked, viewed, n_points, vals);
+    return launched("bff_point_values");
+}
+
+extern "C" int bff_select_unique_rank(const float *sorted, int64_t n, double fraction, int32_t *block_scratch,
+                                      float *thr, int32_t *n_unique, void *stream)
+{
+    BFF_REQUIRE(n >= 0 && sorted && block_scratch && thr && n_unique, "bff_select_unique_rank: bad arguments");
+    const int nb = (int)ceil_div(n > 0 ? n : 1, kSelBlock);
+    if (n > 0) distinct_count_kernel<<<nb, 256, 0, as_stream(stream)>>>(sorted, n, block_scratch);
+    distinct_select_kernel<<<1, 1024, 0, as_stream(stream)>>>(sorted, n, block_scratch, n > 0 ? nb : 0, fraction, thr, n_unique);
+    return launched("bff_select_unique_rank");
 }
 
 extern "C" int bff_ratio_keep(const int32_t *masked, const int32_t *viewed, int64_t n_points, float thr,
-                              int32_t use_thr, int64_t nw, uint64_t *keep, void *stream)
+                              const float *thr_dev, int32_t use_thr, int64_t nw, uint64_t *keep, void *stream)
 {
     BFF_REQUIRE(n_points >= 0 && nw == ceil_div(n_points, 64), "bff_ratio_keep: bad sizes");
     if (n_points == 0) return BFF_OK;
     BFF_REQUIRE(masked && keep, "bff_ratio_keep: null pointer");
-    ratio_keep_kernel<<<(unsigned)ceil_div(nw * 64, 256), 256, 0, as_stream(stream)>>>(masked, viewed, n_points, thr, use_thr, nw, keep);
+    ratio_keep_kernel<<<(unsigned)ceil_div(nw * 64, 256), 256, 0, as_stream(stream)>>>(masked, viewed, n_points, thr, thr_dev, use_thr, nw, keep);
     return launched("bff_ratio_keep");
 }

@@ -161,9 +161,30 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restri
 
 // tmask[t] = OR of the chunk masks of the 64 rows order[64t .. 64t+63]
 __global__ void tile_masks_kernel(const uint64_t *__restrict__ cmask, const int32_t *__restrict__ order, int n,
-                                  int mw, uint64_t *__restrict__ tmask)
+                                  int mw, uint64_t *__restrict__ tmask, const uint32_t *__restrict__ hist,
+                                  uint32_t *__restrict__ hist_sorted, int n_pos, const int32_t *__restrict__ area,
+                                  uint32_t *__restrict__ tile_hmax, int32_t *__restrict__ tile_amin)
 {
     const int t = blockIdx.x;
+    if (hist_sorted) {                                   // hist_sorted[bin][position]: coalesced tile loads
+        const int pos = t * kT + threadIdx.x;
+        const int r = pos < n ? (order ? order[pos] : pos) : -1;
+        for (int b = 0; b < kBins; ++b) hist_sorted[(int64_t)b * n_pos + pos] = r >= 0 ? hist[(int64_t)r * kBins + b] : 0;
+        // per tile: bin-wise maximum over its rows and the smallest non-empty area (tile-level edge bound)
+        uint32_t hm = 0;
+        int amin = 0x7fffffff;
+        for (int k = 0; k < kT; ++k) {
+            const int rr = t * kT + k;
+            if (rr < n) {
+                const int row = order ? order[rr] : rr;
+                hm = max(hm, hist[(int64_t)row * kBins + threadIdx.x]);
+                const int a = area[row];
+                if (a > 0) amin = min(amin, a);
+            }
+        }
+        tile_hmax[(int64_t)t * kBins + threadIdx.x] = hm;
+        if (threadIdx.x == 0) tile_amin[t] = amin;
+    }
     for (int i = threadIdx.x; i < mw; i += blockDim.x) {
         uint64_t v = 0;
         for (int k = 0; k < kT; ++k) {
@@ -355,8 +376,12 @@ __device__ __forceinline__ int uf_find(int32_t *parent, int x)
 {
     int p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (p != x) {
+        const int g = __hip_atomic_load(parent + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // path halving: point x at its grandparent.  g is an ancestor of x, so the forest stays a forest
+        // whatever other waves do meanwhile (links only ever go to smaller indices).
+        if (g != p) __hip_atomic_store(parent + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = p;
-        p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p = g;
     }
     return x;
 }
@@ -387,16 +412,58 @@ __global__ void uf_flatten_kernel(int32_t *parent, int n, int32_t *comp)
     if (i < n) comp[i] = uf_find(parent, i);                      // = smallest row index of the component
 }
 
+// Skeleton pass: one wave per pair of rows `stride` apart in the sorted order.  Rows with the same signature
+// show the same object, so a handful of strides links most of every large component before the tile pass
+// starts, which then finds the bulk of its possible edges already connected.  Exact test, same as the tiles.
+__global__ __launch_bounds__(256) void uf_skeleton_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
+                                                           const int32_t *__restrict__ order,
+                                                           const uint64_t *__restrict__ cmask, int mw,
+                                                           const int32_t *__restrict__ area,
+                                                           const int32_t *__restrict__ label_id, float thr,
+                                                           int32_t *__restrict__ parent, int n_strides)
+{
+    const int lane = lane_id();
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int stride = blockIdx.y < 3 ? blockIdx.y + 1 : (blockIdx.y == 3 ? 5 : blockIdx.y == 4 ? 8 : 13 + 8 * (blockIdx.y - 5));
+    (void)n_strides;
+    if (p + stride >= n) return;
+    const int i = order ? order[p] : p, j = order ? order[p + stride] : p + stride;
+    if (label_id[i] != label_id[j]) return;
+    const uint64_t *ri = rows + (int64_t)i * nw, *rj = rows + (int64_t)j * nw;
+    int acc = 0;
+    for (int m = 0; m < mw; ++m) {                                   // wave-uniform walk over shared chunks
+        uint64_t bits = cmask[(int64_t)i * mw + m] & cmask[(int64_t)j * mw + m];
+        while (bits) {
+            const int c = m * 64 + __ffsll((unsigned long long)bits) - 1;
+            bits &= bits - 1;
+            if (lane < kCW) {
+                const int64_t w = (int64_t)c * kCW + lane;
+                if (w < nw) acc += popc64(ri[w] & rj[w]);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 4; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+    if (lane == 0) {
+        const float fi = (float)acc;
+        const float iou = __fdiv_rn(fi, (float)area[i] + (float)area[j] - fi);
+        if (iou > thr) uf_union(parent, i, j);
+    }
+}
+
 // Tile pairs are enumerated diagonal-first (|bi - bj| = 0, 1, 2, ...): with rows clustered by signature
 // the first tiles discover the large components, and later tiles find most of their possible edges
 // already inside one component and skip their word loop.
 __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
                                                                 const int32_t *__restrict__ order,
                                                                 const uint64_t *__restrict__ tmask, int mw,
-                                                                const uint32_t *__restrict__ hist,
+                                                                const uint32_t *__restrict__ hist, int n_pos,
                                                                 const int32_t *__restrict__ area,
                                                                 const int32_t *__restrict__ label_id, float thr,
-                                                                int32_t *__restrict__ parent, int n_tiles)
+                                                                int32_t *__restrict__ parent, int n_tiles,
+                                                                const uint32_t *__restrict__ tile_hmax,
+                                                                const int32_t *__restrict__ tile_amin,
+                                                                int32_t *__restrict__ diag)
 {
     __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
     __shared__ uint16_t clist[kMaxChunks];
@@ -408,6 +475,24 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
     const int i0 = bi * kT, j0 = bj * kT;
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
     const int n_chunks = (int)((nw + kCW - 1) / kCW);
+
+    // tile-level quick reject: every pair of the tile has I <= u = sum_b min(maxA[b], maxB[b]) and
+    // a_i + a_j >= aminA + aminB, hence IoU = I / (a_i + a_j - I) <= u / (aminA + aminB - u) whenever that
+    // denominator is positive (float32 evaluation is monotone in both arguments); otherwise no conclusion.
+    {
+        const int lane = tid & 63;
+        uint32_t u = min(tile_hmax[(int64_t)bi * kBins + lane], tile_hmax[(int64_t)bj * kBins + lane]);
+#pragma unroll
+        for (int q = 32; q > 0; q >>= 1) u += __shfl_xor(u, q);
+        const int amin_a = tile_amin[bi], amin_b = tile_amin[bj];
+        bool possible = false;
+        if (amin_a != 0x7fffffff && amin_b != 0x7fffffff) {         // a tile of empty rows has no edges at all
+            const float fi = (float)u;
+            const float den = (float)amin_a + (float)amin_b - fi;
+            possible = !(den > 0.0f) || (__fdiv_rn(fi, den) > thr);
+        }
+        if (!possible) return;                                     // block-uniform: every wave computes the same
+    }
 
     if (tid < kT) {
         const int r = i0 + tid;
@@ -422,15 +507,12 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
     uint32_t (*ha)[kBins] = reinterpret_cast<uint32_t (*)[kBins]>(&sa[0][0]);
     uint32_t (*hb)[kBins] = reinterpret_cast<uint32_t (*)[kBins]>(&sb[0][0]);
     {
-        const int lane = tid & 63, wv = tid >> 6;
-        const int ra = i0 + lane, rb = j0 + lane;
-        const uint32_t *ga = ra < n ? hist + (int64_t)(order ? order[ra] : ra) * kBins : nullptr;
-        const uint32_t *gb = rb < n ? hist + (int64_t)(order ? order[rb] : rb) * kBins : nullptr;
+        const int lane = tid & 63, wv = tid >> 6;          // hist is [bin][position]: 256-B coalesced rows
 #pragma unroll
         for (int q = 0; q < kBins / 4; ++q) {
             const int b = wv * (kBins / 4) + q;
-            ha[b][lane] = ga ? ga[b] : 0;
-            hb[b][lane] = gb ? gb[b] : 0;
+            ha[b][lane] = hist[(int64_t)b * n_pos + i0 + lane];
+            hb[b][lane] = hist[(int64_t)b * n_pos + j0 + lane];
         }
     }
     __syncthreads();
@@ -479,6 +561,10 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
     }
     __syncthreads();
     const int cnt = s_cnt;
+    if (diag) {                                                    // diagnostics only (NULL in production)
+        if (tid == 0) { atomicAdd(diag + 0, 1); atomicAdd(diag + 1, cnt); }
+        atomicAdd(diag + 2, __popc(cand));
+    }
     int acc[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -525,7 +611,10 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
                 const int i = rowA[ti * 4 + r], j = rowB[tj * 4 + c];
                 const float fi = (float)acc[r][c];
                 const float iou = __fdiv_rn(fi, (float)area[i] + (float)area[j] - fi);   // P:149-166
-                if (iou > thr) uf_union(parent, i, j);                                   // labels already equal
+                if (iou > thr) {                                                         // labels already equal
+                    uf_union(parent, i, j);
+                    if (diag) atomicAdd(diag + 3, 1);
+                }
             }
 }
 
@@ -742,7 +831,7 @@ extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t
     const int mw = (int)ceil_div(n_chunks, 64);
     // pairs with an empty intersection have IoU 0 (or NaN): they can only be skipped when 0 > thr is false
     const bool sparse = chunk_mask && !(0.0f > iou_thres);
-    if (sparse) tile_masks_kernel<<<nt, 64, 0, as_stream(stream)>>>(chunk_mask, order, n_rows, mw, tile_mask);
+    if (sparse) tile_masks_kernel<<<nt, 64, 0, as_stream(stream)>>>(chunk_mask, order, n_rows, mw, tile_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
     const int aw = nt;   // ceil(n_rows/64) words per adjacency row
     merge_adjacency_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, as_stream(stream)>>>(
         rows, n_rows, nw, order, sparse ? tile_mask : nullptr, mw, (sparse && !inter) ? hist : nullptr, area, label_id,
@@ -752,25 +841,35 @@ extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t
 
 extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
                                     const uint64_t *chunk_mask, uint64_t *tile_mask, const uint32_t *hist,
-                                    const int32_t *area, const int32_t *label_id, float iou_thres,
-                                    int32_t *parent, int32_t *comp, void *stream)
+                                    uint32_t *hist_sorted, const int32_t *area, const int32_t *label_id,
+                                    float iou_thres, int32_t *parent, int32_t init_parent, int32_t *comp,
+                                    int32_t *diag, void *stream)
 {
     BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_merge_components: bad sizes");
     if (n_rows == 0) return BFF_OK;
-    BFF_REQUIRE(rows && chunk_mask && tile_mask && hist && area && label_id && parent && comp && parent != comp,
-                "bff_merge_components: null pointer");
+    BFF_REQUIRE(rows && chunk_mask && tile_mask && hist && hist_sorted && area && label_id && parent && comp &&
+                parent != comp, "bff_merge_components: null pointer");
     const int nt = (int)ceil_div(n_rows, kT);
     BFF_LIMIT((int64_t)nt * (nt + 1) / 2 < (1ll << 31), "bff_merge_components: too many rows");
     const int n_chunks = (int)ceil_div(nw, kCW);
     BFF_LIMIT(n_chunks <= kMaxChunks, "bff_merge_components: more than %d chunks (N > %d points)", kMaxChunks, kMaxChunks * kCW * 64);
     const int mw = (int)ceil_div(n_chunks, 64);
     hipStream_t st = as_stream(stream);
-    uf_init_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows);
+    if (init_parent) uf_init_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows);
     // an empty intersection gives IoU 0 (or NaN): such pairs can only be skipped when 0 > thr is false
     const bool sparse = !(0.0f > iou_thres);
-    if (sparse) tile_masks_kernel<<<nt, 64, 0, st>>>(chunk_mask, order, n_rows, mw, tile_mask);
+    // scratch carved from hist_sorted: [64][nt*64] sorted histograms, then [nt][64] tile maxima, then [nt] min areas
+    uint32_t *tile_hmax = hist_sorted + (size_t)kBins * nt * kT;
+    int32_t *tile_amin = reinterpret_cast<int32_t *>(tile_hmax + (size_t)nt * kBins);
+    tile_masks_kernel<<<nt, 64, 0, st>>>(chunk_mask, order, n_rows, mw, tile_mask, hist, hist_sorted, nt * kT, area,
+                                         tile_hmax, tile_amin);
+    constexpr int kStrides = 8;                                    // 1, 2, 3, 5, 8, 13, 21, 29
+    dim3 sgrid((unsigned)ceil_div(n_rows, 4), kStrides);
+    uf_skeleton_kernel<<<sgrid, 256, 0, st>>>(rows, n_rows, nw, order, chunk_mask, mw, area, label_id, iou_thres, parent,
+                                              kStrides);
     merge_components_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, st>>>(
-        rows, n_rows, nw, order, sparse ? tile_mask : nullptr, mw, hist, area, label_id, iou_thres, parent, nt);
+        rows, n_rows, nw, order, sparse ? tile_mask : nullptr, mw, hist_sorted, nt * kT, area, label_id, iou_thres,
+        parent, nt, tile_hmax, tile_amin, diag);
     uf_flatten_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows, comp);
     return launched("bff_merge_components");
 }

@@ -9,7 +9,6 @@ sets of distinct values, and dict assembly.  `P:` = tools/projection_2d_to_3d.py
 from __future__ import annotations
 
 import dataclasses
-import math
 from typing import List
 
 import numpy as np
@@ -78,22 +77,19 @@ def groups_from_labels(comp: np.ndarray, has_self_loop: np.ndarray, min_members:
     return [m for _, m in out]
 
 
-def _threshold_from_lattice(presence: np.ndarray, v_max: int, fraction: float, ratio: bool) -> np.float32:
-    """unique()[floor(fraction * n_unique)] over the distinct values of masked/(viewed+1) (P:571-576)
-    or of masked (P:513-518), from the set of occurring (masked, viewed) pairs."""
-    cells = np.flatnonzero(presence)
-    m = (cells // (v_max + 1)).astype(np.float32)
-    if ratio:
-        v = (cells % (v_max + 1)).astype(np.float32)
-        vals = m / (v + np.float32(1.0))                 # float32 IEEE division, like torch
-    else:
-        vals = m
-    uniq = np.unique(vals)
-    return uniq[math.floor(fraction * uniq.shape[0])]
+def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, phases=None) -> Stage2Result:
+    """P:402-634 for one uploaded scene.  `phases` (dict, diagnostic): wall time per phase with a device
+    synchronize at every phase boundary."""
+    import time
+    _t = [time.perf_counter()]
 
+    def mark(name):
+        if phases is not None:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            phases[name] = phases.get(name, 0.0) + (now - _t[0])
+            _t[0] = now
 
-def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -> Stage2Result:
-    """P:402-634 for one uploaded scene."""
     dev = ds.xyz.device
     dbg = {}
     n, nw = ds.n_points, ds.nw
@@ -118,6 +114,15 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -
                            ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows if ds.n_rows else None,
                            masked, viewed)
     del maskbits
+    # a14/a15: point filter (P:512-583), entirely on the device: the threshold never visits the host
+    if cfg.if_occurance_threshold or do_ratio:
+        frac = cfg.detected_ratio_threshold if do_ratio else cfg.occurance_threshold
+        thr_dev, lat_info = _lib.point_threshold(masked, viewed if do_ratio else None, frac)
+        keep = _lib.ratio_keep(masked, viewed if do_ratio else None, thr_dev, True)
+    else:
+        thr_dev = lat_info = None
+        keep = _lib.ratio_keep(masked, None, 0.0, False)
+    mark("decode+sweep")
     # per-point arrays and bit rows are in the (spatially sorted) device point order; `unsorted` maps
     # bit rows back to the caller's point order
     unsorted = (lambda r: _lib.permute_bits(r, ds.unsort, n)) if ds.unsort is not None else (lambda r: r)
@@ -137,7 +142,15 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -
         order = order.to(torch.int32)
     with span(timers, "merge_components"):
         comp = _lib.merge_components(rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist)
-        comp_h, area_h = comp.cpu().numpy(), area.cpu().numpy()
+        got = _lib.fetch(comp, area, *([lat_info, thr_dev] if lat_info is not None else []))   # one sync
+        comp_h, area_h = got[0], got[1]
+    if lat_info is not None:
+        if got[2][0] == 0 or np.isnan(got[3][0]):
+            raise IndexError("index out of range: unique()[floor(t * n)] (P:516 / P:574)")
+        dbg["thr"] = float(got[3][0])
+        if debug_out and do_ratio:
+            dbg["viewed_counts"] = back(viewed)
+    mark("stats+components")
     self_loop = (area_h > 0) & bool(np.float32(1.0) > np.float32(cfg.iou_thres))
     groups = groups_from_labels(comp_h, self_loop, cfg.min_aggragated_masks)        # P:203
     dbg["groups"] = groups
@@ -153,27 +166,11 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -
     agg = _lib.or_reduce_groups(rows, offs_d, members_d, max(len(g) for g in merged))
     conf = _lib.group_conf_mean(ds.conf, offs_d, members_d)
     agg_labels = [ds.labels[g[0]] for g in merged]
+    mark("grouping+or_reduce")
     if not debug_out:
         del rows
 
-    # a14/a15: point filter (P:512-583)
-    if cfg.if_occurance_threshold:
-        m_max = int(masked.max().item())
-        pres = _lib.count_lattice(masked, None, m_max, 0).cpu().numpy()
-        thr = _threshold_from_lattice(pres, 0, cfg.occurance_threshold, ratio=False)
-        keep = _lib.ratio_keep(masked, None, thr, True)
-        dbg["thr"] = float(thr)
-    elif do_ratio:
-        m_max = int(masked.max().item())
-        pres = _lib.count_lattice(masked, viewed, m_max, ds.n_viewed).cpu().numpy()
-        thr = _threshold_from_lattice(pres, ds.n_viewed, cfg.detected_ratio_threshold, ratio=True)
-        keep = _lib.ratio_keep(masked, viewed, thr, True)
-        dbg["thr"] = float(thr)
-        if debug_out:
-            dbg["viewed_counts"] = back(viewed)
-    else:
-        keep = _lib.ratio_keep(masked, None, 0.0, False)
-
+    mark("point_filter")
     # a16: overlap resolution (P:592-596).  `groups` (not `merged`) indexes the sizes, as in the
     # reference where num_masks comes from mask_indeces_to_be_merged (P:285) -- identical unless
     # min_aggragated_masks == 0.
@@ -190,6 +187,7 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -
         _lib.apply_row_ops(agg, torch.tensor(ops, dtype=torch.int32).to(dev))
     _lib.and_rows(agg, keep)                                                        # P:595
     after = _lib.popcount_rows(agg)                                                 # P:596
+    mark("overlap")
 
     # a17: size filters with the reference's dtype promotion (int64 vs python scalars, P:601-606)
     before_t, after_t = before.cpu().to(torch.int64), after.cpu().to(torch.int64)
@@ -199,6 +197,7 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -
     out_rows = unsorted(_lib.gather_rows(agg, idx.to(dev))) if idx.numel() else agg[:0]
     out_conf = conf[keep_rows.to(dev)]
     out_labels = [c for c, kk in zip(agg_labels, keep_rows.tolist()) if kk]
+    mark("size_filter+output")
     return Stage2Result(ds.scene_id, n, out_rows, out_conf, out_labels, groups, dbg)
 
 

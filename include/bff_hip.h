@@ -146,16 +146,20 @@ int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const 
  * without the transitive-closure matmuls of find_unconnected_subgraphs_tensor P:250-274.  64x64 tile pairs
  * are visited diagonal-first in `order`; a pair is examined only if the histogram bound allows an edge AND
  * its two rows are not yet in one component; edges found are merged into a disjoint-set forest
- * (`parent`, int32 [n_rows] scratch) with compare-and-swap.  Exact: a pair is skipped only when it cannot
+ * (`parent`, int32 [n_rows]; init_parent != 0: start from singletons, == 0: continue from the forest
+ * already in `parent`, e.g. a coarser partition known to the caller) with compare-and-swap.  Exact: a pair is skipped only when it cannot
  * be an edge or when adding the edge could not change the components.
  * comp (int32 [n_rows], out): comp[i] = smallest row index of i's component.  Rows with an empty
  * adjacency row (area 0, or thr >= 1) form singleton components here; the host turns them into the
  * reference's empty lists (it knows area and thr).  All other arguments as for bff_merge_adjacency;
- * chunk_mask, tile_mask and hist are required. */
+ * chunk_mask, tile_mask and hist are required; hist_sorted is scratch, uint32 [64*64*nt + 65*nt] with
+ * nt = ceil(n_rows/64);
+ * diag (optional, NULL in production): int32 [4], zeroed by the caller, += {tile pairs evaluated, chunks
+ * visited, candidate pairs tested exactly, unions performed}. */
 int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
                          const uint64_t *chunk_mask, uint64_t *tile_mask, const uint32_t *hist,
-                         const int32_t *area, const int32_t *label_id, float iou_thres,
-                         int32_t *parent, int32_t *comp, void *stream);
+                         uint32_t *hist_sorted, const int32_t *area, const int32_t *label_id, float iou_thres,
+                         int32_t *parent, int32_t init_parent, int32_t *comp, int32_t *diag, void *stream);
 
 /* rows_out[r] bit o = rows_in[r] bit idx[o], o < n_out (bit gather).  Undoes the spatial point sort the
  * host applies at upload: idx[o] = position of original point o in the sorted cloud. */
@@ -210,17 +214,21 @@ int bff_rle_to_rows(const int32_t *run_start, const int32_t *run_end, const int3
                     int32_t n_rows, int64_t n_points, int64_t nw, uint64_t *rows, void *stream);
 
 /* ------------------------------------------------------------------------------------------
- * a14/a15 -- point filters.
- * bff_count_lattice: presence[m * (v_max+1) + v] |= 1 for every point with (masked=m, viewed=v):
- * the set of distinct (masked, viewed) pairs, from which the host forms the distinct float32 ratios
- * masked/(viewed+1) and picks unique()[floor(t * n_unique)] exactly like P:571-576 (or P:513-518 with
- * viewed == NULL, v = 0).  presence: uint8 [(m_max+1)*(v_max+1)], zeroed by the caller.
- * bff_ratio_keep: keep bit n = masked[n] > 0 && !((float)masked[n] / ((float)viewed[n] + 1.0f) < thr)
- * (P:571,578,583; viewed == NULL -> keep = masked > 0 && !(masked < thr), P:522). */
-int bff_count_lattice(const int32_t *masked, const int32_t *viewed, int64_t n_points,
-                      int32_t m_max, int32_t v_max, uint8_t *presence, void *stream);
-int bff_ratio_keep(const int32_t *masked, const int32_t *viewed, int64_t n_points, float thr, int32_t use_thr,
-                   int64_t nw, uint64_t *keep, void *stream);
+ * a14/a15 -- point filters (P:512-583), kept entirely on the device.
+ * bff_point_values: vals[n] = (float)masked[n] / ((float)viewed[n] + 1.0f) (P:571; IEEE float32), or
+ * (float)masked[n] when viewed == NULL (P:513).  The caller sorts vals ascending (a library sort, on its
+ * side of the ABI), then bff_select_unique_rank writes *thr = distinct_values[floor(fraction * n_distinct)]
+ * -- the reference's `x.unique()[math.floor(t * x.unique().shape[0])]` (P:516-518, 574-576; float64 product;
+ * NaN when the index is out of range, where python raises IndexError) -- and *n_unique.  block_scratch:
+ * int32 [ceil(n/1024)].
+ * bff_ratio_keep: keep bit n = masked[n] > 0 && !(value[n] < thr) with value as above (P:522,578,583);
+ * the threshold is read from thr_dev (device) when non-NULL, else the immediate `thr`; use_thr == 0 -> keep =
+ * masked > 0. */
+int bff_point_values(const int32_t *masked, const int32_t *viewed, int64_t n_points, float *vals, void *stream);
+int bff_select_unique_rank(const float *sorted, int64_t n, double fraction, int32_t *block_scratch,
+                           float *thr, int32_t *n_unique, void *stream);
+int bff_ratio_keep(const int32_t *masked, const int32_t *viewed, int64_t n_points, float thr,
+                   const float *thr_dev, int32_t use_thr, int64_t nw, uint64_t *keep, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a21/a24 -- cosine similarity GEMM on the matrix cores (MFMA f16 -> f32).

@@ -350,36 +350,37 @@ def test_rle_to_rows_golden(lib):
 
 
 @pytest.mark.parametrize("mode", ["ratio", "occurrence"])
-def test_point_filters(lib, mode):
-    """Threshold = unique()[floor(t * n_unique)] exactly as torch computes it (P:513-518, 571-576)."""
+@pytest.mark.parametrize("n", [1, 1000, 50_000, 200_001])
+def test_point_filters(lib, mode, n):
+    """Threshold = unique()[floor(t * n_unique)] exactly as torch computes it (P:513-518, 571-576), selected
+    and applied on the device."""
     import math
-    from beyond_fixed_forms_amd.projection import _threshold_from_lattice
-    rng = np.random.default_rng(2)
-    n = 50_000
-    masked = rng.integers(0, 40, n) * (rng.random(n) < 0.4)
-    viewed = rng.integers(0, 25, n)
+    rng = np.random.default_rng(n)
+    masked = rng.integers(0, 700, n) * (rng.random(n) < 0.4)
+    viewed = rng.integers(0, 300, n)
     mt, vt = torch.tensor(masked, dtype=torch.float32), torch.tensor(viewed, dtype=torch.float32)
     md = torch.tensor(masked, dtype=torch.int32, device=DEV)
-    vd = torch.tensor(viewed, dtype=torch.int32, device=DEV)
-    if mode == "ratio":
-        ratio = mt / (vt + 1)
-        uniq = ratio.unique()
-        thr = uniq[math.floor(0.38 * uniq.shape[0])]
-        mt[ratio < thr] = 0
-        pres = lib.count_lattice(md, vd, int(masked.max()), 24).cpu().numpy()
-        got_thr = _threshold_from_lattice(pres, 24, 0.38, ratio=True)
-        keep = lib.ratio_keep(md, vd, got_thr, True)
-    else:
-        uniq = mt.unique()
-        thr = uniq[math.floor(0.3 * uniq.shape[0])]
-        mt[mt < thr] = 0
-        pres = lib.count_lattice(md, None, int(masked.max()), 0).cpu().numpy()
-        got_thr = _threshold_from_lattice(pres, 0, 0.3, ratio=False)
-        keep = lib.ratio_keep(md, None, got_thr, True)
-    assert np.float32(got_thr) == thr.numpy()
+    vd = torch.tensor(viewed, dtype=torch.int32, device=DEV) if mode == "ratio" else None
+    frac = 0.38 if mode == "ratio" else 0.3
+    stat = mt / (vt + 1) if mode == "ratio" else mt
+    uniq = stat.unique()
+    thr = uniq[math.floor(frac * uniq.shape[0])]
+    mt[stat < thr] = 0
+    thr_dev, n_unique = lib.point_threshold(md, vd, frac)
+    assert int(n_unique.item()) == uniq.shape[0]
+    assert thr_dev.cpu().numpy()[0] == thr.numpy()
+    keep = lib.ratio_keep(md, vd, thr_dev, True)
     assert np.array_equal(unpack(keep[None], n)[0], (mt > 0).numpy())
+    assert torch.equal(lib.ratio_keep(md, vd, float(thr), True), keep)
     keep0 = lib.ratio_keep(md, None, 0.0, False)
     assert np.array_equal(unpack(keep0[None], n)[0], masked > 0)
+    for f in (0.0, 0.999999, 1.0):          # first, last, out of range (python: IndexError)
+        t2, _ = lib.point_threshold(md, vd, f)
+        k = math.floor(f * uniq.shape[0])
+        if k < uniq.shape[0]:
+            assert t2.cpu().numpy()[0] == uniq[k].numpy()
+        else:
+            assert np.isnan(t2.cpu().numpy()[0])
 
 
 @pytest.mark.parametrize("na,nb,dim", [(1, 198, 768), (37, 200, 64), (300, 198, 512), (16, 16, 32)])

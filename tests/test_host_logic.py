@@ -93,23 +93,6 @@ def test_groups_from_labels_matches_closure_components():
     assert groups_from_labels(np.array([0, 0, 2]), np.array([True, False, False])) == [[0, 1], []]
 
 
-def test_threshold_from_lattice_equals_torch_unique():
-    import math
-    from beyond_fixed_forms_amd.projection import _threshold_from_lattice
-    rng = np.random.default_rng(1)
-    m = rng.integers(0, 30, 5000) * (rng.random(5000) < 0.5)
-    v = rng.integers(0, 12, 5000)
-    pres = np.zeros((m.max() + 1) * 12, np.uint8)
-    pres[m * 12 + v] = 1
-    ratio = torch.tensor(m, dtype=torch.float32) / (torch.tensor(v, dtype=torch.float32) + 1)
-    uniq = ratio.unique()
-    assert _threshold_from_lattice(pres, 11, 0.38, True) == uniq[math.floor(0.38 * len(uniq))].numpy()
-    cnt = torch.tensor(m, dtype=torch.float32).unique()
-    pres1 = np.zeros(m.max() + 1, np.uint8)
-    pres1[m] = 1
-    assert _threshold_from_lattice(pres1, 0, 0.3, False) == cnt[math.floor(0.3 * len(cnt))].numpy()
-
-
 def test_prepare_scene_frame_table_cpu():
     """Frame table / run tables are built on the host; check them without touching a GPU."""
     from beyond_fixed_forms_amd.config import Config

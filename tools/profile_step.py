@@ -43,6 +43,10 @@ for _ in range(10):
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"projection {1e2 * (t1 - t0):.2f} ms/step, refinement {1e2 * (t2 - t1):.2f} ms/step")
+ph = {}
+for _ in range(10):
+    run_projection(ds, cfg, phases=ph)
+print('phases (ms/step, serialised):', {k: round(100 * v, 3) for k, v in ph.items()})
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(10):
