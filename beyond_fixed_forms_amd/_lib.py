@@ -32,6 +32,7 @@ SIGNATURES = {
     "bff_or_reduce_groups": [_P, _L, _P, _P, _I, _I, _P, _P],
     "bff_group_conf_mean": [_P, _I, _P, _P, _I, _P, _P],
     "bff_apply_row_ops": [_P, _L, _P, _I, _P],
+    "bff_overlap_ops": [_P, _P, _I, _P, _P],
     "bff_and_rows": [_P, _I, _L, _P, _P],
     "bff_gather_rows": [_P, _P, _I, _L, _P, _P],
     "bff_unpack_rows": [_P, _I, _L, _L, _P, _P],
@@ -227,6 +228,18 @@ def group_conf_mean(conf, group_offs, members):
 
 def apply_row_ops(rows, ops):
     call("bff_apply_row_ops", _ptr(rows, i64), rows.shape[1], _ptr(ops, i32), ops.shape[0])
+
+
+def resolve_overlaps(rows, sizes):
+    """solve_overlapping P:277-301 on bit rows, in place, without leaving the device.
+    sizes: int32 device tensor, number of raw masks merged into each row."""
+    k = rows.shape[0]
+    if k < 2:
+        return
+    inter = cross_popcount(rows, rows)
+    ops = torch.empty(1 + 3 * (k * (k - 1) // 2), dtype=i32, device=rows.device)
+    call("bff_overlap_ops", _ptr(inter, i32), _ptr(sizes, i32), k, _ptr(ops))
+    call("bff_apply_row_ops", _ptr(rows, i64), rows.shape[1], _ptr(ops), -1)
 
 
 def and_rows(rows, keep):

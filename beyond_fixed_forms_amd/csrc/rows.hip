@@ -684,11 +684,34 @@ __global__ __launch_bounds__(64) void group_conf_mean_kernel(const T *__restrict
 }
 
 // ---- row programs -----------------------------------------------------------------------------
+// Sequential overlap decisions of solve_overlapping (P:285-299) on the device: inter is the K x K
+// intersection matrix of the aggregated rows BEFORE any edit (P:289-292), size[i] the number of raw masks
+// merged into row i; pairs are visited in the reference's order (i ascending, j > i ascending) and the
+// and-not operations appended to `ops` ([0] = count, then (opcode, dst, src) triples).  One thread: K is
+// tens to a few hundred and the list order is the semantics.
+__global__ void overlap_ops_kernel(const int32_t *__restrict__ inter, const int32_t *__restrict__ size, int k,
+                                   int32_t *__restrict__ ops)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    int n = 0;
+    for (int i = 0; i < k; ++i)
+        for (int j = i + 1; j < k; ++j)
+            if (inter[(int64_t)i * k + j] > 0) {
+                const bool i_wins = size[i] > size[j];                 // ties: i loses (P:296-299)
+                ops[1 + 3 * n] = 0;
+                ops[2 + 3 * n] = i_wins ? j : i;
+                ops[3 + 3 * n] = i_wins ? i : j;
+                ++n;
+            }
+    ops[0] = n;
+}
+
 __global__ void apply_row_ops_kernel(uint64_t *__restrict__ rows, int64_t nw, const int32_t *__restrict__ ops,
                                      int n_ops)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nw) return;
+    if (n_ops < 0) { n_ops = ops[0]; ops += 1; }          // device-side list: [count, triples...]
     for (int k = 0; k < n_ops; ++k) {
         const int op = ops[3 * k], d = ops[3 * k + 1], s = ops[3 * k + 2];
         const uint64_t sv = rows[(int64_t)s * nw + w];
@@ -919,9 +942,17 @@ extern "C" int bff_group_conf_mean(const void *conf, int32_t dtype, const int32_
     return launched("bff_group_conf_mean");
 }
 
+extern "C" int bff_overlap_ops(const int32_t *inter, const int32_t *size, int32_t k, int32_t *ops, void *stream)
+{
+    BFF_REQUIRE(k >= 0, "bff_overlap_ops: bad size");
+    BFF_REQUIRE(ops && (k == 0 || (inter && size)), "bff_overlap_ops: null pointer");
+    overlap_ops_kernel<<<1, 64, 0, as_stream(stream)>>>(inter, size, k, ops);
+    return launched("bff_overlap_ops");
+}
+
 extern "C" int bff_apply_row_ops(uint64_t *rows, int64_t nw, const int32_t *ops, int32_t n_ops, void *stream)
 {
-    BFF_REQUIRE(n_ops >= 0 && nw >= 0, "bff_apply_row_ops: bad sizes");
+    BFF_REQUIRE(nw >= 0, "bff_apply_row_ops: bad sizes");
     if (n_ops == 0 || nw == 0) return BFF_OK;
     BFF_REQUIRE(rows && ops, "bff_apply_row_ops: null pointer");
     apply_row_ops_kernel<<<(unsigned)ceil_div(nw, 256), 256, 0, as_stream(stream)>>>(rows, nw, ops, n_ops);

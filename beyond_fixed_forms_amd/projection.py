@@ -46,6 +46,36 @@ class Stage2Result:
                 "final_class": list(self.final_class)}
 
 
+class _LazyGroups(list):
+    """The reference's mask_indeces_to_be_merged (list of lists), materialised from CSR on first use --
+    building ~10^4 Python ints per scene is not needed on the hot path."""
+
+    def __init__(self, offs, members):
+        super().__init__()
+        self._csr = (offs, members)
+
+    def _fill(self):
+        if self._csr is not None:
+            offs, members = self._csr
+            self._csr = None
+            super().extend(members[offs[g]:offs[g + 1]].tolist() for g in range(len(offs) - 1))
+
+    def __len__(self):
+        return len(self._csr[0]) - 1 if self._csr is not None else super().__len__()
+
+    def __iter__(self):
+        self._fill(); return super().__iter__()
+
+    def __getitem__(self, i):
+        self._fill(); return super().__getitem__(i)
+
+    def __eq__(self, other):
+        self._fill(); return list.__eq__(self, other)
+
+    def __repr__(self):
+        self._fill(); return super().__repr__()
+
+
 def _empty(ds: DeviceScene, debug) -> Stage2Result:
     debug["empty_form"] = True
     return Stage2Result(ds.scene_id, ds.n_points, torch.zeros((0, ds.nw), dtype=torch.int64, device=ds.xyz.device),
@@ -75,6 +105,35 @@ def groups_from_labels(comp: np.ndarray, has_self_loop: np.ndarray, min_members:
     out = [(int(first[g]), [] if void[g] else order[starts[g]:ends[g]].tolist()) for g in keep]
     out.sort(key=lambda kv: kv[0])
     return [m for _, m in out]
+
+
+def component_csr(comp: np.ndarray, has_self_loop: np.ndarray, min_members: int):
+    """Component ids -> the groups merge_masks keeps (P:203-226) in CSR form, without Python lists:
+    (offs int32 [K+1], members int32, sizes int32 [K], n_void).  Same order and content as
+    groups_from_labels(...): components by smallest member, members ascending; a singleton without a
+    self loop is the reference's empty list `[]` -- it has length 0, so it survives the filter only for
+    min_members <= 0, where it is skipped when merging (P:216-217) but still occupies a slot of
+    mask_indeces_to_be_merged; n_void reports how many there are (callers treat that rare config on the
+    slow path)."""
+    n = comp.shape[0]
+    order = np.argsort(comp, kind="stable")
+    cs = comp[order]
+    cut = np.flatnonzero(cs[1:] != cs[:-1]) + 1
+    starts = np.concatenate([np.zeros(1, np.int64), cut])
+    ends = np.concatenate([cut, np.array([n], np.int64)])
+    size = ends - starts
+    first = order[starts]
+    void = (size == 1) & ~has_self_loop[first]
+    keep = ~void & (size >= max(min_members, 1))
+    rank = np.argsort(first[keep], kind="stable")            # groups ordered by their smallest member
+    st, en = starts[keep][rank], ends[keep][rank]
+    sizes = (en - st).astype(np.int32)
+    offs = np.zeros(sizes.size + 1, dtype=np.int32)
+    np.cumsum(sizes, out=offs[1:])
+    # members = concatenation of order[st[g]:en[g]]
+    idx = np.repeat(st - offs[:-1], sizes) + np.arange(offs[-1])
+    members = order[idx].astype(np.int32)
+    return offs, members, sizes, int(void.sum()) if min_members <= 0 else 0
 
 
 def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, phases=None) -> Stage2Result:
@@ -152,53 +211,56 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, p
             dbg["viewed_counts"] = back(viewed)
     mark("stats+components")
     self_loop = (area_h > 0) & bool(np.float32(1.0) > np.float32(cfg.iou_thres))
-    groups = groups_from_labels(comp_h, self_loop, cfg.min_aggragated_masks)        # P:203
-    dbg["groups"] = groups
-    merged = [g for g in groups if g != []]                                         # P:216-217
-    if not merged:                                                                  # P:230-236, 496-509
+    offs, members, sizes, n_void = component_csr(comp_h, self_loop, cfg.min_aggragated_masks)     # P:203
+    if n_void:      # min_aggragated_masks <= 0 keeps empty components in the size list (P:285): exact, slower path
+        groups = groups_from_labels(comp_h, self_loop, cfg.min_aggragated_masks)
+        size_list = [len(g) for g in groups]
+    else:
+        groups, size_list = None, None
+    k_groups = sizes.shape[0]
+    if k_groups == 0:                                                               # P:230-236, 496-509
+        dbg["groups"] = [] if groups is None else groups
         return _empty(ds, dbg)
 
     # a13: OR of member rows, sequential mean of confidences, label of the first member (P:214-226)
-    offs = np.zeros(len(merged) + 1, dtype=np.int32)
-    np.cumsum([len(g) for g in merged], out=offs[1:])
-    members = np.concatenate([np.asarray(g, dtype=np.int32) for g in merged])
     offs_d, members_d = torch.from_numpy(offs).to(dev), torch.from_numpy(members).to(dev)
-    agg = _lib.or_reduce_groups(rows, offs_d, members_d, max(len(g) for g in merged))
+    agg = _lib.or_reduce_groups(rows, offs_d, members_d, int(sizes.max()))
     conf = _lib.group_conf_mean(ds.conf, offs_d, members_d)
-    agg_labels = [ds.labels[g[0]] for g in merged]
-    mark("grouping+or_reduce")
+    first_member = members[offs[:-1]]
+    agg_labels = [ds.labels[i] for i in first_member]
     if not debug_out:
         del rows
+    mark("grouping+or_reduce")
 
-    mark("point_filter")
-    # a16: overlap resolution (P:592-596).  `groups` (not `merged`) indexes the sizes, as in the
-    # reference where num_masks comes from mask_indeces_to_be_merged (P:285) -- identical unless
-    # min_aggragated_masks == 0.
+    # a16: overlap resolution (P:592-596), decided and applied on the device
     before = _lib.popcount_rows(agg)                                                # P:592
-    k = agg.shape[0]
-    inter = _lib.cross_popcount(agg, agg).cpu().numpy()
-    size = [len(g) for g in groups]
-    ops = []
-    for i in range(k):
-        for j in range(i + 1, k):
-            if inter[i, j] > 0:                                                     # P:291 (state before any edit)
-                ops.append((0, j, i) if size[i] > size[j] else (0, i, j))           # P:296-299
-    if ops:
-        _lib.apply_row_ops(agg, torch.tensor(ops, dtype=torch.int32).to(dev))
+    if size_list is None:
+        _lib.resolve_overlaps(agg, torch.from_numpy(sizes).to(dev))                 # P:594
+    else:           # sizes indexed like mask_indeces_to_be_merged, which still holds the empty components
+        inter = _lib.cross_popcount(agg, agg).cpu().numpy()
+        k = agg.shape[0]
+        ops = [(0, j, i) if size_list[i] > size_list[j] else (0, i, j)
+               for i in range(k) for j in range(i + 1, k) if inter[i, j] > 0]
+        if ops:
+            _lib.apply_row_ops(agg, torch.tensor(ops, dtype=torch.int32).to(dev))
     _lib.and_rows(agg, keep)                                                        # P:595
     after = _lib.popcount_rows(agg)                                                 # P:596
     mark("overlap")
 
     # a17: size filters with the reference's dtype promotion (int64 vs python scalars, P:601-606)
-    before_t, after_t = before.cpu().to(torch.int64), after.cpu().to(torch.int64)
+    before_h, after_h = _lib.fetch(before, after)                                   # the second (last) sync
+    before_t, after_t = torch.from_numpy(before_h).to(torch.int64), torch.from_numpy(after_h).to(torch.int64)
     keep_rows = (after_t > cfg.remove_small_masks) & (after_t > cfg.remove_filtered_masks * before_t)
     idx = torch.nonzero(keep_rows).view(-1).to(torch.int32)
     dbg.update(before=before_t, after=after_t, keep=keep_rows)
-    out_rows = unsorted(_lib.gather_rows(agg, idx.to(dev))) if idx.numel() else agg[:0]
-    out_conf = conf[keep_rows.to(dev)]
+    idx_d = idx.to(dev)
+    out_rows = unsorted(_lib.gather_rows(agg, idx_d)) if idx.numel() else agg[:0]
+    out_conf = conf[idx_d.long()]
     out_labels = [c for c, kk in zip(agg_labels, keep_rows.tolist()) if kk]
     mark("size_filter+output")
-    return Stage2Result(ds.scene_id, n, out_rows, out_conf, out_labels, groups, dbg)
+    lazy = _LazyGroups(offs, members) if groups is None else groups
+    dbg["groups"] = lazy
+    return Stage2Result(ds.scene_id, n, out_rows, out_conf, out_labels, lazy, dbg)
 
 
 def project_scene(scene, cfg, device="cuda", return_result: bool = False, debug_out: bool = False):

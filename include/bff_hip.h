@@ -191,8 +191,15 @@ int bff_group_conf_mean(const void *conf, int32_t dtype, const int32_t *group_of
  * ops: int32 [n_ops][3] = (opcode, dst, src) executed in order;
  *   opcode 0: rows[dst] &= ~rows[src]   (solve_overlapping P:295-299)
  *   opcode 1: rows[dst] |=  rows[src]   (stage-1 duplicate merge R:248)
- *   opcode 2: rows[dst]  =  rows[src] */
+ *   opcode 2: rows[dst]  =  rows[src]
+ * n_ops < 0: the list lives on the device as [count, triples...] (as written by bff_overlap_ops). */
 int bff_apply_row_ops(uint64_t *rows, int64_t nw, const int32_t *ops, int32_t n_ops, void *stream);
+
+/* a16: the pair loop of solve_overlapping P:285-299 without a host round trip.  inter = K x K intersections
+ * of the aggregated rows before any edit (bff_cross_popcount), size[i] = number of raw masks merged into row
+ * i (P:285).  ops (int32 [1 + 3*K*(K-1)/2]) receives [count, (0, loser, winner)...] in the reference's pair
+ * order: the row built from fewer masks loses the overlap, ties: the first row loses. */
+int bff_overlap_ops(const int32_t *inter, const int32_t *size, int32_t k, int32_t *ops, void *stream);
 
 /* a16: rows[r] &= keep for r < n_rows                                                   (P:595) */
 int bff_and_rows(uint64_t *rows, int32_t n_rows, int64_t nw, const uint64_t *keep, void *stream);

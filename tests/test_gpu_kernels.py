@@ -332,6 +332,23 @@ def test_row_ops_and_rows(lib):
     assert np.array_equal(unpack(rows, n), exp & keep)
 
 
+def test_resolve_overlaps_golden(lib):
+    """solve_overlapping (P:277-301) decided and applied on the device == the reference's results."""
+    z = Z("agg_helpers.npz")
+    for case in ("ovl_equal", "ovl_mixed", "ovl_none"):
+        n = int(z[f"{case}.n"])
+        rows = pack_np(gio.unpack_bool_rows(z[f"{case}.ins"], n))
+        lib.resolve_overlaps(rows, torch.tensor(z[f"{case}.sizes"], dtype=torch.int32, device=DEV))
+        assert np.array_equal(unpack(rows, n), gio.unpack_bool_rows(z[f"{case}.resolved"], n)), case
+    rng = np.random.default_rng(9)
+    d = rng.random((23, 3000)) < 0.15
+    sizes = rng.integers(2, 6, 23)
+    exp = pref.resolve_overlaps(torch.from_numpy(d.copy()), [list(range(s)) for s in sizes]).numpy()
+    rows = pack_np(d)
+    lib.resolve_overlaps(rows, torch.tensor(sizes, dtype=torch.int32, device=DEV))
+    assert np.array_equal(unpack(rows, 3000), exp)
+
+
 def test_rle_to_rows_golden(lib):
     from beyond_fixed_forms_amd.scene import runs_from_rles
     z = Z("refine_helpers.npz")

@@ -87,6 +87,13 @@ def test_groups_from_labels_matches_closure_components():
                 label[i] = comp[0]
         assert groups_from_labels(label.astype(np.int32), alive) == exp
         assert groups_from_labels(label.astype(np.int32), alive, 2) == [g for g in exp if len(g) >= 2]
+        from beyond_fixed_forms_amd.projection import component_csr
+        for mm in (0, 1, 2, 3):
+            offs, members, sizes, n_void = component_csr(label.astype(np.int32), alive, mm)
+            want = [g for g in exp if len(g) >= max(mm, 1)]
+            assert [members[offs[g]:offs[g + 1]].tolist() for g in range(len(sizes))] == want
+            assert sizes.tolist() == [len(g) for g in want]
+            assert n_void == (sum(1 for g in exp if g == []) if mm <= 0 else 0)
     # a node without a self loop that has a neighbour is a normal member (iou_thres < 0 with an empty mask)
     a = np.array([[1, 1, 0], [1, 0, 0], [0, 0, 0]], bool)
     assert pref.connected_groups(torch.from_numpy(a).float()) == [[0, 1], []]
