@@ -105,8 +105,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # BFF_REHEARSE_ON_ONE_GPU=1: all ranks share cuda:0 and the collectives run over gloo -- only to rehearse
+    # the N > 1 code path on a single-GPU box; the driver's runs use one GPU per rank over RCCL.
+    rehearse = os.environ.get("BFF_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
@@ -124,6 +132,8 @@ def main():
     sim = TextSimilarity(enc, dev)
     t_setup = time.perf_counter() - t0
     exchange = (lambda sims: bdist.exchange_similarities(sims, device=dev)) if world > 1 else None
+    if world > 1:
+        dist.barrier()
 
     timers = KernelTimers()
 
@@ -152,7 +162,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

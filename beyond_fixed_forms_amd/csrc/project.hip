@@ -86,10 +86,20 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
             if (count_viewed) vcount[j] += vis ? 1 : 0;
             if (mimg) {
                 mcount[j] += (sizeof(WordT) == 8) ? __popcll((uint64_t)w) : __popc((uint32_t)w);
+                // lane b collects the ballot of bit b.  Most waves see no mask at all in a given frame, and
+                // the others only a few of its masks: OR the words across the wave and visit the set bits.
                 uint64_t mine = 0;
-                for (int b = 0; b < nm; ++b) {            // nm is wave-uniform
-                    const uint64_t bal = __ballot((w >> b) & 1);
-                    if (lane == b) mine = bal;
+                if (__ballot(w != 0)) {                     // wave-uniform
+                    WordT present = w;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) present |= __shfl_xor(present, d);
+                    while (present) {
+                        const int b = (sizeof(WordT) == 8) ? __ffsll((unsigned long long)present) - 1
+                                                           : __ffs((unsigned)present) - 1;
+                        present &= present - 1;
+                        const uint64_t bal = __ballot((w >> b) & 1);
+                        if (lane == b) mine = bal;
+                    }
                 }
                 if (lane < nm) stage[lane][wave + 4 * j] = mine;
             }

@@ -19,6 +19,11 @@ import torch.distributed as dist
 MAX_SIMS = 256          # a class meets at most one similarity per ScanNet200 label (198) per query
 
 
+def _coll_device(t: torch.Tensor):
+    """RCCL (backend "nccl") moves device tensors; gloo (CPU tests, single-GPU rehearsals) needs host copies."""
+    return t if dist.get_backend() == "nccl" else t.cpu()
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -51,6 +56,7 @@ def exchange_similarities(local_sims: List[List[float]], device="cpu") -> List[L
     buf[0] = len(uniq)
     if uniq:
         buf[1:1 + len(uniq)] = torch.tensor(uniq, dtype=torch.float64)
+    buf = _coll_device(buf)
     out = [torch.empty_like(buf) for _ in range(ws)]
     dist.all_gather(out, buf)
     return [o[1:1 + int(o[0].item())].tolist() for o in out]
@@ -63,15 +69,17 @@ def gather_final_rows(rows: torch.Tensor, dst: int = 0):
     if ws == 1:
         return [rows]
     dev = rows.device
-    shape = torch.tensor([rows.shape[0], rows.shape[1]], dtype=torch.int64, device=dev)
+    shape = _coll_device(torch.tensor([rows.shape[0], rows.shape[1]], dtype=torch.int64, device=dev))
     shapes = [torch.empty_like(shape) for _ in range(ws)]
     dist.all_gather(shapes, shape)
+    shapes = [s.cpu() for s in shapes]
     r_max = max(int(s[0]) for s in shapes)
     w_max = max(int(s[1]) for s in shapes)
     pad = torch.zeros((max(r_max, 1), max(w_max, 1)), dtype=torch.int64, device=dev)
     pad[:rows.shape[0], :rows.shape[1]] = rows
+    pad = _coll_device(pad)
     bufs = [torch.empty_like(pad) for _ in range(ws)] if rank == dst else None
     dist.gather(pad, bufs, dst=dst)
     if rank != dst:
         return None
-    return [b[:int(s[0]), :int(s[1])].clone() for b, s in zip(bufs, shapes)]
+    return [b[:int(s[0]), :int(s[1])].to(dev) for b, s in zip(bufs, shapes)]
