@@ -93,14 +93,55 @@ def cpu_baseline(scene, cfg, enc, n_sample_views=12):
             "sample_seconds": t2 - t0}
 
 
+MFMA_F16_PEAK_TFLOPS = 2500.0     # dense f16/bf16 MFMA peak of MI355X (MI355X_MICROARCH.md; not the 2:1 sparse figure)
+
+
+def bench_cosine(args):
+    """BASELINE config 5: CLIP ViT-L/14 768-d features x 200-class text bank on the MFMA path.
+    One step = cos(A x 768, 200 x 768) for A = 9000 features (the instance count of config 2)."""
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    _lib.load()
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(9000, 768, generator=g).half().to(dev)
+    b = torch.randn(200, 768, generator=g).half().to(dev)
+    for _ in range(args.warmup):
+        _lib.cosine_gemm_f16(a, b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        out = _lib.cosine_gemm_f16(a, b)
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / args.steps
+    flop = 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
+    ref = (a.double() @ b.double().T) / (a.double().norm(dim=1, keepdim=True) * b.double().norm(dim=1, keepdim=True).T)
+    err = float((out.double() - ref).abs().max())
+    tf = flop / (ms * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "cosine GEMMs/sec (9000x768 f16 features x 200x768 f16 text bank)", "value": args.steps / elapsed,
+        "unit": "gemms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "c5: 9000 x 768 f16 features against a 200 x 768 f16 bank, f32 accumulate + normalise"},
+        "roofline": {"bound": "mfma", "kernel": "cosine_gemm_f16_kernel", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                     "note": "2.8 GFLOP per launch: far too small to fill 256 CUs (SURVEY section 8d); launch-latency bound"},
+        "max_abs_err_vs_f64": err}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--shape", default="c2", choices=list(SHAPES))
+    ap.add_argument("--shape", default="c2", choices=list(SHAPES) + ["c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.shape == "c5":
+        return bench_cosine(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -189,7 +230,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "project_views_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": pv[2], "launches": pv[0]},
-            "kernels_ms": {k: round(vv[2], 4) for k, vv in ks.items()},
+            "kernels_ms": {k: round(vv[2], 4) for k, vv in ks.items()},   # HIP-event spans (merge_components includes its read-back)
             "result": {"stage2_instances": int(res.rows.shape[0]),
                        "final_masks": int(fin[scene.scene_id].rows.shape[0]) if fin[scene.scene_id].rows is not None else 0,
                        "merged_groups": len(res.groups)},

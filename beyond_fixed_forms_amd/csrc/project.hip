@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
     int64_t n_pixels, WordT *__restrict__ maskbits)
 {
     __shared__ WordT bits[kChunk];
-    __shared__ WordT wave_tot[kBlock / kWave];
+    __shared__ WordT wave_tot[2][2 * kBlock / kWave];  // [parity][half * 4 + wave]; double buffered across chunks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int v = blockIdx.y;
     const int g0 = view_mask_offs[v];
@@ -147,7 +147,11 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
     const int64_t band0 = (int64_t)blockIdx.x * kChunk * kChunksPerBand;
     WordT *img = maskbits + (int64_t)v * n_pixels;
 
+    // Thread b < nm walks mask b's runs; the current and the next run stay in registers so that a chunk
+    // costs no dependent global loads unless the cursor advances (and then the load is already in flight).
+    constexpr int64_t kNone = INT64_MAX;
     int cur = 0, hi = 0;
+    int64_t rs = kNone, re = kNone, ns = kNone, ne = kNone;
     if (tid < nm) {
         int lo = mask_run_offs[g0 + tid];
         hi = mask_run_offs[g0 + tid + 1];
@@ -157,51 +161,74 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
             if ((int64_t)run_end[mid] > band0) r = mid; else lo = mid + 1;
         }
         cur = r;
+        if (cur < hi) { rs = run_start[cur]; re = run_end[cur]; }
+        if (cur + 1 < hi) { ns = run_start[cur + 1]; ne = run_end[cur + 1]; }
     }
+    // Word ownership: thread t owns words [4t, 4t+4) of each 1024-word half of the chunk, so that one
+    // store instruction of a wave covers 1 KiB contiguously (16 B per lane).
+    constexpr int kHalf = kChunk / 2, kQ = 4;
+#pragma unroll
+    for (int k = 0; k < kQ; ++k) { bits[tid * kQ + k] = 0; bits[kHalf + tid * kQ + k] = 0; }
+    __syncthreads();
     for (int c = 0; c < kChunksPerBand; ++c) {
         const int64_t c0 = band0 + (int64_t)c * kChunk;
         if (c0 >= n_pixels) break;
         const int64_t c1 = min(c0 + kChunk, n_pixels);
-#pragma unroll
-        for (int k = 0; k < kChunk / kBlock; ++k) bits[tid + k * kBlock] = 0;
-        __syncthreads();
         if (tid < nm) {
             const WordT bit = (WordT)1 << tid;
-            while (cur < hi) {
-                const int64_t s = run_start[cur], e = run_end[cur];
-                if (s >= c1) break;
-                const int ls = (int)(max(s, c0) - c0);
-                atomicXor(&bits[ls], bit);
-                if (e < c1) atomicXor(&bits[(int)(e - c0)], bit);
-                if (e > c1) break;                    // run continues into the next chunk
+            while (rs < c1) {
+                atomicXor(&bits[(int)(max(rs, c0) - c0)], bit);
+                if (re < c1) atomicXor(&bits[(int)(re - c0)], bit);
+                if (re > c1) break;                   // run continues into the next chunk
                 ++cur;
+                rs = ns; re = ne;
+                if (cur + 1 < hi) { ns = run_start[cur + 1]; ne = run_end[cur + 1]; } else { ns = ne = kNone; }
             }
         }
         __syncthreads();
-        // XOR prefix scan: 8 consecutive words per thread, wave scan of the thread totals
-        WordT loc[kChunk / kBlock];
-        WordT acc = 0;
+        // XOR prefix scan of the two halves; words are re-zeroed as they are read
+        WordT loc[2][kQ], tot[2];
 #pragma unroll
-        for (int k = 0; k < kChunk / kBlock; ++k) { acc ^= bits[tid * (kChunk / kBlock) + k]; loc[k] = acc; }
-        WordT incl = acc;
+        for (int h = 0; h < 2; ++h) {
+            WordT acc = 0;
+#pragma unroll
+            for (int k = 0; k < kQ; ++k) {
+                acc ^= bits[h * kHalf + tid * kQ + k];
+                loc[h][k] = acc;
+                bits[h * kHalf + tid * kQ + k] = 0;
+            }
+            tot[h] = acc;
+        }
+        WordT incl[2] = {tot[0], tot[1]};
 #pragma unroll
         for (int d = 1; d < kWave; d <<= 1) {
-            const WordT up = __shfl_up(incl, d);
-            if (lane >= d) incl ^= up;
+            const WordT u0 = __shfl_up(incl[0], d), u1 = __shfl_up(incl[1], d);
+            if (lane >= d) { incl[0] ^= u0; incl[1] ^= u1; }
         }
-        if (lane == kWave - 1) wave_tot[wave] = incl;
-        __syncthreads();
-        WordT carry = incl ^ acc;                     // exclusive prefix within the wave
-        for (int q = 0; q < wave; ++q) carry ^= wave_tot[q];
+        if (lane == kWave - 1) { wave_tot[c & 1][wave] = incl[0]; wave_tot[c & 1][4 + wave] = incl[1]; }
+        __syncthreads();                              // also orders the re-zeroing before the next toggles
+        WordT carry0 = incl[0] ^ tot[0], carry1 = incl[1] ^ tot[1];          // exclusive within the wave
+        for (int q = 0; q < wave; ++q) { carry0 ^= wave_tot[c & 1][q]; carry1 ^= wave_tot[c & 1][4 + q]; }
+        for (int q = 0; q < 4; ++q) carry1 ^= wave_tot[c & 1][q];            // second half continues the first
+        using Vec = __attribute__((ext_vector_type(4))) uint32_t;
 #pragma unroll
-        for (int k = 0; k < kChunk / kBlock; ++k) bits[tid * (kChunk / kBlock) + k] = loc[k] ^ carry;
-        __syncthreads();
+        for (int h = 0; h < 2; ++h) {
+            const WordT carry = h ? carry1 : carry0;
+            const int64_t p0 = c0 + h * kHalf + (int64_t)tid * kQ;
+            WordT outv[kQ];
 #pragma unroll
-        for (int k = 0; k < kChunk / kBlock; ++k) {
-            const int64_t p = c0 + tid + k * kBlock;
-            if (p < c1) img[p] = bits[tid + k * kBlock];
+            for (int k = 0; k < kQ; ++k) outv[k] = loc[h][k] ^ carry;
+            if (p0 + kQ <= c1) {
+                const Vec *src = reinterpret_cast<const Vec *>(outv);
+                Vec *dst = reinterpret_cast<Vec *>(img + p0);      // chunk starts are multiples of 2048 words
+#pragma unroll
+                for (int k = 0; k < (int)(kQ * sizeof(WordT) / 16); ++k) dst[k] = src[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < kQ; ++k)
+                    if (p0 + k < c1) img[p0 + k] = outv[k];
+            }
         }
-        __syncthreads();
     }
 }
 

@@ -431,19 +431,27 @@ __global__ __launch_bounds__(256) void uf_skeleton_kernel(const uint64_t *__rest
     if (label_id[i] != label_id[j]) return;
     const uint64_t *ri = rows + (int64_t)i * nw, *rj = rows + (int64_t)j * nw;
     int acc = 0;
+    const int sub = lane >> 3, cw = lane & 7;                        // 8 chunks x 8 words per step
     for (int m = 0; m < mw; ++m) {                                   // wave-uniform walk over shared chunks
         uint64_t bits = cmask[(int64_t)i * mw + m] & cmask[(int64_t)j * mw + m];
         while (bits) {
-            const int c = m * 64 + __ffsll((unsigned long long)bits) - 1;
-            bits &= bits - 1;
-            if (lane < kCW) {
-                const int64_t w = (int64_t)c * kCW + lane;
+            int mine = -1;                                           // the sub-th set bit of this batch, if any
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (bits) {
+                    const int c = __ffsll((unsigned long long)bits) - 1;
+                    bits &= bits - 1;
+                    if (k == sub) mine = m * 64 + c;
+                }
+            }
+            if (mine >= 0) {
+                const int64_t w = (int64_t)mine * kCW + cw;
                 if (w < nw) acc += popc64(ri[w] & rj[w]);
             }
         }
     }
 #pragma unroll
-    for (int d = 4; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
     if (lane == 0) {
         const float fi = (float)acc;
         const float iou = __fdiv_rn(fi, (float)area[i] + (float)area[j] - fi);
