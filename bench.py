@@ -62,9 +62,11 @@ def bank_encoder(bank, index):
     return enc
 
 
-def cpu_baseline(scene, cfg, enc, n_sample_views=12):
-    """Oracle (CPU restatement of the reference) on a bounded sample: the first `n_sample_views`
-    frames of the same scene at full N / HxW / M, whole path; scaled linearly to the scene's views."""
+def cpu_baseline(scene, cfg, enc, n_sample_views=100):
+    """Oracle (CPU restatement of the reference) on a bounded sample (~10-30 s of CPU work): the first
+    `n_sample_views` frames of the same scene at full N / HxW / M, whole path (projection, aggregation of
+    the sample's instances, ratio sweep, filters, refinement); the projection time is scaled linearly to the
+    scene's views, which favours the CPU (its aggregation grows quadratically with the instance count)."""
     from oracle.projection_ref import project_scene_ref
     from oracle.refinement_ref import refine_class_ref
     torch.set_num_threads(16)
