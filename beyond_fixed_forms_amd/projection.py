@@ -70,7 +70,12 @@ class _LazyGroups(list):
         self._fill(); return super().__getitem__(i)
 
     def __eq__(self, other):
-        self._fill(); return list.__eq__(self, other)
+        self._fill()
+        if isinstance(other, _LazyGroups):
+            other._fill()
+        return list.__eq__(self, other)
+
+    __hash__ = None
 
     def __repr__(self):
         self._fill(); return super().__repr__()
