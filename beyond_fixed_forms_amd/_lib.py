@@ -25,7 +25,7 @@ SIGNATURES = {
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
     "bff_row_stats": [_P, _I, _L, _P, _P, _P, _P, _P, _P],
-    "bff_merge_components": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P],
+    "bff_merge_components": [_P, _I, _L, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P],
     "bff_merge_adjacency": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "bff_permute_bits": [_P, _I, _L, _P, _L, _L, _P, _P],
     "bff_components_round": [_P, _I, _P, _P, _P, _P],
@@ -155,24 +155,35 @@ def row_stats(rows):
     return area, mean_word, cmask, hist, sig
 
 
-def merge_components(rows, area, label_id, iou_thres, order, chunk_mask, hist, diag=None, parent=None):
-    """comp[i] = smallest row index of the component of row i in the merge graph (one pass, no adjacency)."""
+def merge_components(rows, area, label_id, iou_thres, order, chunk_mask, hist, diag=None, parent=None,
+                     coarse_stride=0):
+    """comp[i] = smallest row index of the component of row i in the merge graph (no adjacency matrix).
+    coarse_stride > 1 (optional, off by default: measured slower at config 2): the tile pass first runs on
+    every coarse_stride-th row of `order`, then the full pass starts from that forest."""
     n = rows.shape[0]
-    tmask = torch.empty(((n + 63) // 64, chunk_mask.shape[1]), dtype=i64, device=rows.device)
+    nt = (n + 63) // 64
+    tmask = torch.empty((nt, chunk_mask.shape[1]), dtype=i64, device=rows.device)
     init = parent is None
     if init:
         parent = torch.empty(n, dtype=i32, device=rows.device)
     comp = torch.empty(n, dtype=i32, device=rows.device)
-    nt = (n + 63) // 64
     hist_sorted = torch.empty(64 * 64 * nt + 65 * nt, dtype=i32, device=rows.device)      # scratch, see bff_hip.h
-    call("bff_merge_components", _ptr(rows, i64), n, rows.shape[1], _ptr(order, i32), _ptr(chunk_mask, i64),
-         _ptr(tmask), _ptr(hist, i32), _ptr(hist_sorted), _ptr(area, i32), _ptr(label_id, i32), float(iou_thres),
-         _ptr(parent), int(init), _ptr(comp), _ptr(diag, i32))
+
+    def run(ordr, init_parent, out):
+        call("bff_merge_components", _ptr(rows, i64), n, rows.shape[1], _ptr(ordr, i32), ordr.shape[0],
+             _ptr(chunk_mask, i64), _ptr(tmask), _ptr(hist, i32), _ptr(hist_sorted), _ptr(area, i32),
+             _ptr(label_id, i32), float(iou_thres), _ptr(parent), int(init_parent), _ptr(out), _ptr(diag, i32))
+
+    if init and coarse_stride > 1 and n >= 64 * coarse_stride:
+        run(order[::coarse_stride].contiguous(), True, None)
+        run(order, False, comp)
+    else:
+        run(order, init, comp)
     return comp
 
 
 def merge_adjacency(rows, area, label_id, iou_thres, order=None, chunk_mask=None, hist=None, want_inter=False):
-    """Adjacency bit matrix indexed by position in `order` (identity when None)."""
+    """Adjacency bit matrix indexed by position in `order` (identity when None).  Cross-check path."""
     n = rows.shape[0]
     aw = (n + 63) // 64
     adj = torch.empty((n, aw), dtype=i64, device=rows.device)

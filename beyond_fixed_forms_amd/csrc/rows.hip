@@ -555,7 +555,16 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
     const int any_candidate = __syncthreads_or(cand != 0);
     if (!any_candidate) return;                                    // block-uniform
 
-    if (tid < kWave) {
+    // ---- compact the candidate pairs of the tile: (row index in A) << 8 | (row index in B)
+    __shared__ uint16_t plist[kT * kT];
+    __shared__ int wbase[4];
+    const int lane = tid & 63, wv = tid >> 6;
+    const int mine_n = __popc(cand);
+    int incl = mine_n;
+#pragma unroll
+    for (int q = 1; q < 64; q <<= 1) { const int up = __shfl_up(incl, q); if (lane >= q) incl += up; }
+    if (lane == 63) wbase[wv] = incl;
+    if (tid < kWave) {                                             // chunk list, meanwhile
         int base = 0;
         for (int m = 0; m < (n_chunks + 63) / 64; ++m) {
             const uint64_t bits = tmask ? (tmask[(int64_t)bi * mw + m] & tmask[(int64_t)bj * mw + m]) : ~0ull;
@@ -568,27 +577,43 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
         if (tid == 0) s_cnt = base;
     }
     __syncthreads();
+    int pos = incl - mine_n;
+    for (int q = 0; q < wv; ++q) pos += wbase[q];
+    const int n_pairs = wbase[0] + wbase[1] + wbase[2] + wbase[3];
+    {
+        unsigned cc = cand;
+        while (cc) {
+            const int q = __ffs(cc) - 1;
+            cc &= cc - 1;
+            plist[pos++] = (uint16_t)(((ti * 4 + (q >> 2)) << 8) | (tj * 4 + (q & 3)));
+        }
+    }
+    __syncthreads();
     const int cnt = s_cnt;
     if (diag) {                                                    // diagnostics only (NULL in production)
-        if (tid == 0) { atomicAdd(diag + 0, 1); atomicAdd(diag + 1, cnt); }
-        atomicAdd(diag + 2, __popc(cand));
+        if (tid == 0) { atomicAdd(diag + 0, 1); atomicAdd(diag + 1, cnt); atomicAdd(diag + 2, n_pairs); }
     }
-    int acc[4][4];
+    const int lk = tid & (kKW - 1), lr = tid >> 5;
+    const int slot = lk / kCW, cw = lk % kCW;
+    const uint64_t *pa[8];
+    const uint64_t *pb[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int q = 0; q < 8; ++q) {
+        const int ra = rowA[lr + 8 * q], rb = rowB[lr + 8 * q];
+        pa[q] = ra >= 0 ? rows + (int64_t)ra * nw : nullptr;
+        pb[q] = rb >= 0 ? rows + (int64_t)rb * nw : nullptr;
+    }
+    constexpr int kSparse = 3;                                     // pair-list path: at most 3 pairs per thread
+    if (n_pairs <= kSparse * 256) {
+        // few candidates: accumulate only those pairs (2 LDS reads per pair word)
+        int pi[kSparse], pj[kSparse], accs[kSparse];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0;
-    {
-        const int lk = tid & (kKW - 1), lr = tid >> 5;
-        const int slot = lk / kCW, cw = lk % kCW;
-        const uint64_t *pa[8];
-        const uint64_t *pb[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int ra = rowA[lr + 8 * q], rb = rowB[lr + 8 * q];
-            pa[q] = ra >= 0 ? rows + (int64_t)ra * nw : nullptr;
-            pb[q] = rb >= 0 ? rows + (int64_t)rb * nw : nullptr;
+        for (int q = 0; q < kSparse; ++q) {
+            const int p = tid + q * 256;
+            const int code = p < n_pairs ? plist[p] : 0;
+            pi[q] = code >> 8; pj[q] = code & 255; accs[q] = 0;
         }
+        const int n_mine = (n_pairs - tid + 255) / 256;            // pairs this thread really owns (<= kSparse)
         for (int g = 0; g < cnt; g += kKW / kCW) {
             const int64_t w = (g + slot < cnt) ? (int64_t)clist[g + slot] * kCW + cw : nw;
             const bool kin = w < nw;
@@ -598,18 +623,55 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
                 sb[lk][lr + 8 * q] = (kin && pb[q]) ? pb[q][w] : 0;
             }
             __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kSparse; ++q)
+                if (q < n_mine) {
+                    int a2 = 0;
 #pragma unroll 8
-            for (int kk = 0; kk < kKW; ++kk) {
-                uint64_t av[4], bv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { av[r] = sa[kk][ti * 4 + r]; bv[r] = sb[kk][tj * 4 + r]; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[r][c] += popc64(av[r] & bv[c]);
-            }
+                    for (int kk = 0; kk < kKW; ++kk) a2 += popc64(sa[kk][pi[q]] & sb[kk][pj[q]]);
+                    accs[q] += a2;
+                }
             __syncthreads();
         }
+#pragma unroll
+        for (int q = 0; q < kSparse; ++q)
+            if (q < n_mine) {
+                const int i = rowA[pi[q]], j = rowB[pj[q]];
+                const float fi = (float)accs[q];
+                const float iou = __fdiv_rn(fi, (float)area[i] + (float)area[j] - fi);   // P:149-166
+                if (iou > thr) {
+                    uf_union(parent, i, j);
+                    if (diag) atomicAdd(diag + 3, 1);
+                }
+            }
+        return;
+    }
+    // many candidates: full 4x4 register blocks
+    int acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+    for (int g = 0; g < cnt; g += kKW / kCW) {
+        const int64_t w = (g + slot < cnt) ? (int64_t)clist[g + slot] * kCW + cw : nw;
+        const bool kin = w < nw;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sa[lk][lr + 8 * q] = (kin && pa[q]) ? pa[q][w] : 0;
+            sb[lk][lr + 8 * q] = (kin && pb[q]) ? pb[q][w] : 0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < kKW; ++kk) {
+            uint64_t av[4], bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { av[r] = sa[kk][ti * 4 + r]; bv[r] = sb[kk][tj * 4 + r]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] += popc64(av[r] & bv[c]);
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -871,37 +933,39 @@ extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t
 }
 
 extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
-                                    const uint64_t *chunk_mask, uint64_t *tile_mask, const uint32_t *hist,
-                                    uint32_t *hist_sorted, const int32_t *area, const int32_t *label_id,
-                                    float iou_thres, int32_t *parent, int32_t init_parent, int32_t *comp,
-                                    int32_t *diag, void *stream)
+                                    int32_t n_order, const uint64_t *chunk_mask, uint64_t *tile_mask,
+                                    const uint32_t *hist, uint32_t *hist_sorted, const int32_t *area,
+                                    const int32_t *label_id, float iou_thres, int32_t *parent, int32_t init_parent,
+                                    int32_t *comp, int32_t *diag, void *stream)
 {
-    BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_merge_components: bad sizes");
+    BFF_REQUIRE(n_rows >= 0 && nw >= 0 && n_order >= 0 && n_order <= n_rows, "bff_merge_components: bad sizes");
     if (n_rows == 0) return BFF_OK;
-    BFF_REQUIRE(rows && chunk_mask && tile_mask && hist && hist_sorted && area && label_id && parent && comp &&
-                parent != comp, "bff_merge_components: null pointer");
-    const int nt = (int)ceil_div(n_rows, kT);
+    BFF_REQUIRE(rows && chunk_mask && tile_mask && hist && hist_sorted && area && label_id && parent &&
+                (order || n_order == n_rows), "bff_merge_components: null pointer");
+    const int nt = (int)ceil_div(n_order, kT);
     BFF_LIMIT((int64_t)nt * (nt + 1) / 2 < (1ll << 31), "bff_merge_components: too many rows");
     const int n_chunks = (int)ceil_div(nw, kCW);
     BFF_LIMIT(n_chunks <= kMaxChunks, "bff_merge_components: more than %d chunks (N > %d points)", kMaxChunks, kMaxChunks * kCW * 64);
     const int mw = (int)ceil_div(n_chunks, 64);
     hipStream_t st = as_stream(stream);
     if (init_parent) uf_init_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows);
-    // an empty intersection gives IoU 0 (or NaN): such pairs can only be skipped when 0 > thr is false
-    const bool sparse = !(0.0f > iou_thres);
-    // scratch carved from hist_sorted: [64][nt*64] sorted histograms, then [nt][64] tile maxima, then [nt] min areas
-    uint32_t *tile_hmax = hist_sorted + (size_t)kBins * nt * kT;
-    int32_t *tile_amin = reinterpret_cast<int32_t *>(tile_hmax + (size_t)nt * kBins);
-    tile_masks_kernel<<<nt, 64, 0, st>>>(chunk_mask, order, n_rows, mw, tile_mask, hist, hist_sorted, nt * kT, area,
-                                         tile_hmax, tile_amin);
-    constexpr int kStrides = 8;                                    // 1, 2, 3, 5, 8, 13, 21, 29
-    dim3 sgrid((unsigned)ceil_div(n_rows, 4), kStrides);
-    uf_skeleton_kernel<<<sgrid, 256, 0, st>>>(rows, n_rows, nw, order, chunk_mask, mw, area, label_id, iou_thres, parent,
-                                              kStrides);
-    merge_components_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, st>>>(
-        rows, n_rows, nw, order, sparse ? tile_mask : nullptr, mw, hist_sorted, nt * kT, area, label_id, iou_thres,
-        parent, nt, tile_hmax, tile_amin, diag);
-    uf_flatten_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows, comp);
+    if (n_order > 0) {
+        // an empty intersection gives IoU 0 (or NaN): such pairs can only be skipped when 0 > thr is false
+        const bool sparse = !(0.0f > iou_thres);
+        // scratch carved from hist_sorted: [64][nt*64] sorted histograms, then [nt][64] tile maxima, then [nt] min areas
+        uint32_t *tile_hmax = hist_sorted + (size_t)kBins * nt * kT;
+        int32_t *tile_amin = reinterpret_cast<int32_t *>(tile_hmax + (size_t)nt * kBins);
+        tile_masks_kernel<<<nt, 64, 0, st>>>(chunk_mask, order, n_order, mw, tile_mask, hist, hist_sorted, nt * kT, area,
+                                             tile_hmax, tile_amin);
+        constexpr int kStrides = 8;                                    // 1, 2, 3, 5, 8, 13, 21, 29
+        dim3 sgrid((unsigned)ceil_div(n_order, 4), kStrides);
+        uf_skeleton_kernel<<<sgrid, 256, 0, st>>>(rows, n_order, nw, order, chunk_mask, mw, area, label_id, iou_thres,
+                                                  parent, kStrides);
+        merge_components_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, st>>>(
+            rows, n_order, nw, order, sparse ? tile_mask : nullptr, mw, hist_sorted, nt * kT, area, label_id, iou_thres,
+            parent, nt, tile_hmax, tile_amin, diag);
+    }
+    if (comp) uf_flatten_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows, comp);
     return launched("bff_merge_components");
 }
 

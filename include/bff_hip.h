@@ -149,14 +149,17 @@ int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const 
  * (`parent`, int32 [n_rows]; init_parent != 0: start from singletons, == 0: continue from the forest
  * already in `parent`, e.g. a coarser partition known to the caller) with compare-and-swap.  Exact: a pair is skipped only when it cannot
  * be an edge or when adding the edge could not change the components.
- * comp (int32 [n_rows], out): comp[i] = smallest row index of i's component.  Rows with an empty
+ * `order` may list only n_order <= n_rows of the rows (a sample): only pairs among the listed rows are
+ * examined, which is how the caller builds a coarse forest first (every 8th row) and then refines it with the
+ * full order and init_parent = 0.  comp (int32 [n_rows], out, may be NULL): comp[i] = smallest row index of
+ * i's component.  Rows with an empty
  * adjacency row (area 0, or thr >= 1) form singleton components here; the host turns them into the
  * reference's empty lists (it knows area and thr).  All other arguments as for bff_merge_adjacency;
  * chunk_mask, tile_mask and hist are required; hist_sorted is scratch, uint32 [64*64*nt + 65*nt] with
  * nt = ceil(n_rows/64);
  * diag (optional, NULL in production): int32 [4], zeroed by the caller, += {tile pairs evaluated, chunks
  * visited, candidate pairs tested exactly, unions performed}. */
-int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
+int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order, int32_t n_order,
                          const uint64_t *chunk_mask, uint64_t *tile_mask, const uint32_t *hist,
                          uint32_t *hist_sorted, const int32_t *area, const int32_t *label_id, float iou_thres,
                          int32_t *parent, int32_t init_parent, int32_t *comp, int32_t *diag, void *stream);

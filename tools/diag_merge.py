@@ -28,6 +28,11 @@ for name, o in (("signature", o_sig), ("mean_word", o_mean), ("identity", o_id))
 timeit("row_stats", lambda: _lib.row_stats(rows))
 timeit("argsort(sig)", lambda: torch.argsort(sig, stable=True))
 
+for cs in (0, 4, 8, 16):
+    timeit(f"merge_components signature thr=0.2 coarse_stride={cs}", lambda: _lib.merge_components(rows, area, ds.label_id, 0.2, o_sig, cmask, hist, coarse_stride=cs))
+    d = torch.zeros(4, dtype=torch.int32, device=dev)
+    _lib.merge_components(rows, area, ds.label_id, 0.2, o_sig, cmask, hist, diag=d, coarse_stride=cs)
+    print("   coarse", cs, "tiles evaluated, chunk visits, candidate pairs, unions:", d.tolist())
 for name, o in (("signature", o_sig), ("mean_word", o_mean)):
     for thr in (0.2, 0.9):
         d = torch.zeros(4, dtype=torch.int32, device=dev)
