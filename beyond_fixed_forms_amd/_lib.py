@@ -38,6 +38,8 @@ SIGNATURES = {
     "bff_unpack_rows": [_P, _I, _L, _L, _P, _P],
     "bff_pack_rows": [_P, _I, _L, _L, _P, _P],
     "bff_rle_to_rows": [_P, _P, _P, _I, _L, _L, _P, _P],
+    "bff_rle_count_runs": [_P, _I, _L, _P, _P],
+    "bff_rle_encode_rows": [_P, _I, _L, _P, _L, _P, _P],
     "bff_ratio_keep": [_P, _P, _L, _F, _P, _I, _L, _P, _P],
     "bff_point_values": [_P, _P, _L, _P, _P],
     "bff_select_unique_rank": [_P, _L, _D, _P, _P, _P, _P],
@@ -285,6 +287,25 @@ def rle_to_rows(run_start, run_end, row_run_offs, n_points):
     rows = torch.empty((k, nw), dtype=i64, device=run_start.device)
     call("bff_rle_to_rows", _ptr(run_start, i32), _ptr(run_end, i32), _ptr(row_run_offs, i32), k, n_points, nw, _ptr(rows))
     return rows
+
+
+def rows_to_rle(rows, n_points):
+    """Bit rows -> list of {"length", "counts"} in the reference's RLE format (rle_encode_batch RLE:10-32)."""
+    import numpy as np
+    k = rows.shape[0]
+    if k == 0:
+        return []
+    n_runs = torch.empty(k, dtype=i32, device=rows.device)
+    call("bff_rle_count_runs", _ptr(rows, i64), k, rows.shape[1], _ptr(n_runs))
+    nr = n_runs.cpu().numpy().astype(np.int64)
+    offs = np.zeros(k + 1, dtype=np.int64)
+    np.cumsum(nr, out=offs[1:])
+    total = int(offs[-1])
+    counts = torch.empty(2 * total, dtype=i64, device=rows.device)
+    call("bff_rle_encode_rows", _ptr(rows, i64), k, rows.shape[1], _ptr(torch.from_numpy(offs[:-1].copy()).to(rows.device)),
+         total, _ptr(counts))
+    flat = counts.cpu().numpy()
+    return [dict(length=int(n_points), counts=flat[2 * offs[r]:2 * offs[r + 1]].copy()) for r in range(k)]
 
 
 def point_threshold(masked, viewed, fraction):

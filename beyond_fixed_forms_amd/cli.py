@@ -38,7 +38,10 @@ def projection_main(argv=None):
         if not res.debug.get("empty_form", False):
             ckpt[scene_id] = True                                                         # P:580-581
             write_scene_checkpoint("projection_2d_to_3d", cls, ckpt)
-        save_result(res.to_dict(), cfg.mask_3d_dir, cls, scene_id)                          # P:630-634
+        # BFF_SAVE_RLE=1 stores "ins" as RLE dicts (Open3DIS format; refinement.py and eval_scannet200.py:123-124
+        # read both forms) instead of the reference's dense bool matrix
+        out = res.to_rle_dict() if os.environ.get("BFF_SAVE_RLE") == "1" and not res.debug.get("empty_form") else res.to_dict()
+        save_result(out, cfg.mask_3d_dir, cls, scene_id)                                    # P:630-634
     return 0
 
 
@@ -80,7 +83,7 @@ def refinement_main(argv=None):
             scenes.append((scene_id, None, None))
     out = refine_class(scenes, cfg, cls, sim, "cuda")
     for scene_id, res in out.items():
-        d = res.to_dict()
+        d = res.to_rle_dict() if os.environ.get("BFF_SAVE_RLE") == "1" else res.to_dict()
         d = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in d.items()}               # reference saves CPU tensors
         save_result(d, cfg.final_output_dir, cls, scene_id)                                 # R:422-426
         if res.rows is not None and len(res.final_class):

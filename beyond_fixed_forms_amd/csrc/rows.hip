@@ -855,6 +855,77 @@ __global__ void rle_to_rows_kernel(const int32_t *__restrict__ run_start, const 
     rows[(int64_t)g * nw + w] = v;
 }
 
+// ---- bit rows -> 1-D RLE (rle_encode_batch, rle_encode_decode.py:10-32) ------------------------------
+// A run starts at point p iff bit p is set and bit p-1 is not; it ends (exclusive) at e iff bit e-1 is set
+// and bit e is not.  Padding bits are zero and one virtual zero word follows the row, so a run reaching the
+// last point ends at N like any other.  Starts and ends alternate: the k-th end closes the k-th start.
+// Pass 1 counts the starts per row; pass 2 writes counts[2k] = start+1 (1-based) and counts[2k+1] = end,
+// rank by rank (block scan of the per-word counts); pass 3 turns the ends into lengths.
+__device__ __forceinline__ void rle_word_edges(const uint64_t *row, int64_t w, int64_t nw, uint64_t &starts,
+                                               uint64_t &ends)
+{
+    const uint64_t cur = w < nw ? row[w] : 0;
+    const uint64_t prev_bit = w ? (row[w - 1] >> 63) : 0;
+    const uint64_t shifted = (cur << 1) | prev_bit;             // bit p = value of point p-1
+    starts = cur & ~shifted;
+    ends = ~cur & shifted;
+}
+
+__global__ __launch_bounds__(256) void rle_count_kernel(const uint64_t *__restrict__ rows, int64_t nw,
+                                                         int32_t *__restrict__ n_runs)
+{
+    __shared__ int part[4];
+    const uint64_t *row = rows + (int64_t)blockIdx.x * nw;
+    int c = 0;
+    for (int64_t w = threadIdx.x; w < nw; w += 256) {
+        uint64_t st, en;
+        rle_word_edges(row, w, nw, st, en);
+        c += popc64(st);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if (lane_id() == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) n_runs[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void rle_write_kernel(const uint64_t *__restrict__ rows, int64_t nw,
+                                                         const int64_t *__restrict__ run_offs,
+                                                         int64_t *__restrict__ counts)
+{
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t *row = rows + (int64_t)blockIdx.x * nw;
+    int64_t *out = counts + 2 * run_offs[blockIdx.x];
+    int base_st = 0, base_en = 0;
+    for (int64_t w0 = 0; w0 <= nw; w0 += 256) {                  // <= : includes the virtual word nw
+        const int64_t w = w0 + tid;
+        uint64_t st = 0, en = 0;
+        if (w <= nw) rle_word_edges(row, w, nw, st, en);
+        const int packed = popc64(st) | (popc64(en) << 16);      // <= 32 starts / ends per word, 256 words: no carry
+        int incl = packed;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int excl = incl - packed;
+        for (int q = 0; q < wave; ++q) excl += wsum[q];
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        int64_t rs = base_st + (excl & 0xFFFF), re = base_en + (excl >> 16);
+        while (st) { const int b = __ffsll((unsigned long long)st) - 1; st &= st - 1; out[2 * rs++] = w * 64 + b + 1; }
+        while (en) { const int b = __ffsll((unsigned long long)en) - 1; en &= en - 1; out[2 * re++ + 1] = w * 64 + b; }
+        base_st += total & 0xFFFF;
+        base_en += total >> 16;
+        __syncthreads();
+    }
+}
+
+__global__ void rle_lengths_kernel(int64_t *__restrict__ counts, int64_t n_runs_total)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_runs_total) counts[2 * k + 1] -= counts[2 * k] - 1;       // end - start(0-based)
+}
+
 }  // namespace bff
 
 using namespace bff;
@@ -1083,4 +1154,24 @@ extern "C" int bff_rle_to_rows(const int32_t *run_start, const int32_t *run_end,
     dim3 grid((unsigned)ceil_div(nw, 256), (unsigned)n_rows);
     rle_to_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(run_start, run_end, row_run_offs, n_points, nw, rows);
     return launched("bff_rle_to_rows");
+}
+
+extern "C" int bff_rle_count_runs(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *n_runs, void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_rle_count_runs: bad sizes");
+    if (n_rows == 0) return BFF_OK;
+    BFF_REQUIRE(rows && n_runs, "bff_rle_count_runs: null pointer");
+    rle_count_kernel<<<n_rows, 256, 0, as_stream(stream)>>>(rows, nw, n_runs);
+    return launched("bff_rle_count_runs");
+}
+
+extern "C" int bff_rle_encode_rows(const uint64_t *rows, int32_t n_rows, int64_t nw, const int64_t *run_offs,
+                                   int64_t n_runs_total, int64_t *counts, void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && nw >= 0 && n_runs_total >= 0, "bff_rle_encode_rows: bad sizes");
+    if (n_rows == 0 || n_runs_total == 0) return BFF_OK;
+    BFF_REQUIRE(rows && run_offs && counts, "bff_rle_encode_rows: null pointer");
+    rle_write_kernel<<<n_rows, 256, 0, as_stream(stream)>>>(rows, nw, run_offs, counts);
+    rle_lengths_kernel<<<(unsigned)ceil_div(n_runs_total, 256), 256, 0, as_stream(stream)>>>(counts, n_runs_total);
+    return launched("bff_rle_encode_rows");
 }

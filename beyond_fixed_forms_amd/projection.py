@@ -45,6 +45,12 @@ class Stage2Result:
         return {"ins": _lib.unpack_rows(self.rows, self.n_points), "conf": self.conf,
                 "final_class": list(self.final_class)}
 
+    def to_rle_dict(self):
+        """Same result with "ins" as a list of RLE dicts (the Open3DIS stage-1 storage format,
+        rle_encode_batch RLE:10-32), encoded on the device."""
+        return {"ins": _lib.rows_to_rle(self.rows, self.n_points), "conf": self.conf,
+                "final_class": list(self.final_class)}
+
 
 class _LazyGroups(list):
     """The reference's mask_indeces_to_be_merged (list of lists), materialised from CSR on first use --

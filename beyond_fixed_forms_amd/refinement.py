@@ -65,7 +65,12 @@ def _stage2_rows(stage2, n_points, device):
     conf = stage2["conf"]
     if len(conf) == 0:                                                              # R:196
         return torch.zeros((0, (n_points + 63) // 64), dtype=torch.int64, device=device), torch.as_tensor(conf).cpu()
-    ins = stage2["ins"].to(device)
+    ins = stage2["ins"]
+    if isinstance(ins, list):                       # stored as RLE dicts (Stage2Result.to_rle_dict / BFF_SAVE_RLE=1)
+        rs, re, offs = runs_from_rles(ins, "stage-2")
+        t = lambda a: torch.from_numpy(a).to(device)
+        return _lib.rle_to_rows(t(rs), t(re), t(offs), n_points), torch.as_tensor(conf).cpu()
+    ins = ins.to(device)
     if ins.dtype not in (torch.bool, torch.uint8):
         ins = ins != 0
     return _lib.pack_rows(ins.contiguous()), conf.cpu()
@@ -199,6 +204,12 @@ class FinalResult:
         if self.rows is None:
             return {"ins": [], "conf": [], "final_class": list(self.final_class)}
         return {"ins": _lib.unpack_rows(self.rows, self.n_points), "conf": self.conf,
+                "final_class": list(self.final_class)}
+
+    def to_rle_dict(self):
+        """Same result with "ins" as RLE dicts (what eval_scannet200.py:123-124 also accepts), encoded on the device."""
+        rows = self.rows if self.rows is not None else None
+        return {"ins": [] if rows is None else _lib.rows_to_rle(rows, self.n_points), "conf": self.conf,
                 "final_class": list(self.final_class)}
 
 

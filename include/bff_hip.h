@@ -223,6 +223,15 @@ int bff_pack_rows(const uint8_t *dense, int32_t n_rows, int64_t n_points, int64_
 int bff_rle_to_rows(const int32_t *run_start, const int32_t *run_end, const int32_t *row_run_offs,
                     int32_t n_rows, int64_t n_points, int64_t nw, uint64_t *rows, void *stream);
 
+/* SURVEY section 8f row 1 -- bit rows -> 1-D RLE in the reference's format (rle_encode_batch RLE:10-32: 1-based
+ * start, length pairs), so results can be stored like Open3DIS stage-1 files (eval_scannet200.py:123-124 reads
+ * them).  bff_rle_count_runs: n_runs[r] = number of runs of row r.  The host turns that into exclusive offsets
+ * run_offs (int64 [n_rows]) and a total; bff_rle_encode_rows then fills counts (int64 [2 * n_runs_total]) with
+ * row r's pairs at counts[2*run_offs[r] ...].  Padding bits of the rows must be zero (they always are here). */
+int bff_rle_count_runs(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *n_runs, void *stream);
+int bff_rle_encode_rows(const uint64_t *rows, int32_t n_rows, int64_t nw, const int64_t *run_offs,
+                        int64_t n_runs_total, int64_t *counts, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * a14/a15 -- point filters (P:512-583), kept entirely on the device.
  * bff_point_values: vals[n] = (float)masked[n] / ((float)viewed[n] + 1.0f) (P:571; IEEE float32), or

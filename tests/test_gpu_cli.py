@@ -75,6 +75,17 @@ def test_stage_scripts_end_to_end(tmp_path):
     ck = yaml.safe_load((tmp_path / "checkpoints" / f"projection_2d_to_3d_checkpoint_{cls}.yaml").read_text())
     assert ck == {sc.scene_id: True for sc in scenes}
     assert (tmp_path / "checkpoints" / f"refinement_checkpoint_{cls}.yaml").exists()
+    # same run storing RLE instead of dense masks: identical content
+    env_rle = dict(env, BFF_SAVE_RLE="1")
+    for script in ("projection_2d_to_3d.py", "refinement.py"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), "--config", str(tmp_path / "config.yaml"),
+                            "--cls", cls], cwd=tmp_path, env=env_rle, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+    from oracle.rle_ref import rle_decode_ref
+    for sc in scenes:
+        got = torch.load(tmp_path / "final" / cls / f"{sc.scene_id}.pth", map_location="cpu", weights_only=False)
+        dec = np.stack([rle_decode_ref(r) for r in got["ins"]]).astype(bool)
+        assert np.array_equal(dec, fexp[sc.scene_id]["ins"].numpy())
     # a failing stage must exit non-zero (run_evl.py relies on subprocess.run(check=True))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "projection_2d_to_3d.py"), "--config",
                         str(tmp_path / "config.yaml"), "--cls", "no such class"], cwd=tmp_path, capture_output=True)

@@ -349,6 +349,25 @@ def test_resolve_overlaps_golden(lib):
     assert np.array_equal(unpack(rows, 3000), exp)
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 128, 10_001, 16_384 + 64, 200_000])
+def test_rows_to_rle_matches_reference_encoder(lib, n):
+    """Device RLE encoder == rle_encode_batch (RLE:10-32), incl. runs touching either end, word-aligned
+    lengths, empty and full rows; decode(encode(x)) == x through the device decoder too."""
+    from beyond_fixed_forms_amd.scene import runs_from_rles
+    rng = np.random.default_rng(n)
+    d = np.stack([rng.random(n) < p for p in (0.0, 1.0, 0.5, 0.02, 0.98)] +
+                 [np.repeat(rng.random(n // 37 + 1) < 0.5, 37)[:n], np.arange(n) % 2 == 0, np.arange(n) % 2 == 1])
+    d[3, 0] = d[3, -1] = True
+    rows = pack_np(d)
+    got = lib.rows_to_rle(rows, n)
+    exp = rle_ref.rle_encode_batch_ref(torch.from_numpy(d))
+    for g, e in zip(got, exp):
+        assert g["length"] == e["length"] == n and np.array_equal(g["counts"], e["counts"])
+    rs, re, offs = runs_from_rles(got)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    assert torch.equal(lib.rle_to_rows(t(rs), t(re), t(offs), n), rows)
+
+
 def test_rle_to_rows_golden(lib):
     from beyond_fixed_forms_amd.scene import runs_from_rles
     z = Z("refine_helpers.npz")
