@@ -82,8 +82,31 @@ def load():
     return lib
 
 
+_stream_cache = None      # (c_void_p, torch stream) pinned for the duration of a `with launch_stream():` block
+
+
 def _stream():
+    if _stream_cache is not None:
+        return _stream_cache[0]
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class launch_stream:
+    """Look torch's current stream up once for a whole sequence of kernel launches (the lookup costs more
+    than a launch).  Entry points such as run_projection / refine_class wrap their bodies in it; the stream
+    must not be switched inside the block."""
+
+    def __enter__(self):
+        global _stream_cache
+        self._outer = _stream_cache
+        st = torch.cuda.current_stream()
+        _stream_cache = (c_void_p(st.cuda_stream), st)
+        return self
+
+    def __exit__(self, *exc):
+        global _stream_cache
+        _stream_cache = self._outer
+        return False
 
 
 def _ptr(t, dtype=None):
@@ -323,13 +346,24 @@ def point_threshold(masked, viewed, fraction):
     return thr, n_unique
 
 
+_pinned = {}
+
+
 def fetch(*tensors):
-    """Device tensors -> numpy arrays with ONE stream synchronisation (pinned staging, async copies)."""
-    host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
-    for h, t in zip(host, tensors):
-        h.copy_(t, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
-    return [h.numpy() for h in host]
+    """Device tensors -> numpy arrays with ONE stream synchronisation (async copies into reused pinned
+    staging buffers; the returned arrays are copies, so the staging can be reused by the next call)."""
+    host = []
+    for k, t in enumerate(tensors):
+        key = (k, t.dtype, t.numel())
+        buf = _pinned.get(key)
+        if buf is None:
+            if len(_pinned) > 256:
+                _pinned.clear()
+            buf = _pinned[key] = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+        buf.copy_(t.reshape(-1), non_blocking=True)
+        host.append((buf, t.shape))
+    (_stream_cache[1] if _stream_cache is not None else torch.cuda.current_stream()).synchronize()
+    return [b.numpy().reshape(shape).copy() for b, shape in host]
 
 
 def ratio_keep(masked, viewed, thr, use_thr):

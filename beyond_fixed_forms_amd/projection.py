@@ -150,6 +150,11 @@ def component_csr(comp: np.ndarray, has_self_loop: np.ndarray, min_members: int)
 def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, phases=None) -> Stage2Result:
     """P:402-634 for one uploaded scene.  `phases` (dict, diagnostic): wall time per phase with a device
     synchronize at every phase boundary."""
+    with _lib.launch_stream():
+        return _run_projection(ds, cfg, debug_out, timers, phases)
+
+
+def _run_projection(ds: DeviceScene, cfg, debug_out, timers, phases) -> Stage2Result:
     import time
     _t = [time.perf_counter()]
 

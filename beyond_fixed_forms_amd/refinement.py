@@ -133,12 +133,13 @@ def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: Text
         other = [i for i, lab in enumerate(s1_labels) if lab == query_us]
         return _SceneState(scene_id, n, [], [], None, None, [], _lib.gather_rows(s1, i32(other)) if other else s1[:0])
 
-    area1 = _lib.popcount_rows(s1).cpu()
-    area2 = _lib.popcount_rows(s2).cpu()
-    iou = _iou(_lib.cross_popcount(s1, s2).cpu(), area1, area2)                     # R:208  (K, S1)
+    area1, area2, inter = (torch.from_numpy(a) for a in
+                           _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2), _lib.cross_popcount(s1, s2)))
+    iou = _iou(inter, area1, area2)                                                 # R:208  (K, S1)
     best = torch.argmax(iou, dim=1)                                                 # R:211
     b32 = best.to(torch.int32).to(device)
-    m_iou = _iou(_lib.cross_popcount(s1, s1, b32, b32).cpu(), area1[best], area1[best])   # R:217
+    m_inter = torch.from_numpy(_lib.fetch(_lib.cross_popcount(s1, s1, b32, b32))[0])
+    m_iou = _iou(m_inter, area1[best], area1[best])                                 # R:217
     k = len(best)
     m_iou[range(k), range(k)] = 0                                                   # R:221
     m_adj = (m_iou > cfg.stage1_iou_thres).to(int)                                  # R:224
@@ -177,9 +178,9 @@ def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: Text
         s2 = _lib.or_reduce_groups(s2, torch.from_numpy(offs).to(device),
                                    i32([p for part in parts for p in part]), max(len(p) for p in parts))
 
-    area1 = _lib.popcount_rows(s1).cpu()                                            # stage-1 rows may have grown
-    area2 = _lib.popcount_rows(s2).cpu()
-    iou = _iou(_lib.cross_popcount(s1, s2).cpu(), area1, area2)                     # R:285
+    area1, area2, inter = (torch.from_numpy(a) for a in                              # stage-1 rows may have grown
+                           _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2), _lib.cross_popcount(s1, s2)))
+    iou = _iou(inter, area1, area2)                                                 # R:285
     best = torch.argmax(iou, dim=1)                                                 # R:288
     best_l = best.tolist()
     other = [i for i, lab in enumerate(s1_labels) if lab == query_us and i not in best_l]   # R:293
@@ -265,6 +266,11 @@ def refine_class(scenes, cfg, text_prompt: str, sim: TextSimilarity, device="cud
     multi-GPU driver widen the similarity set of pass 1 to all ranks (the one cross-scene
     dependency of the path, R:316-324).  Returns {scene_id: FinalResult}."""
     _lib.load()
+    with _lib.launch_stream():
+        return _refine_class(scenes, cfg, text_prompt, sim, device, exchange_sims, return_debug)
+
+
+def _refine_class(scenes, cfg, text_prompt, sim, device, exchange_sims, return_debug):
     query_us = text_prompt.replace(" ", "_")                                        # R:142
     states = []
     for scene_id, stage1, stage2 in scenes:                                         # R:166
