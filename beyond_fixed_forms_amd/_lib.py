@@ -20,8 +20,8 @@ _P, _I, _L, _D, _F = c_void_p, c_int32, c_int64, c_double, c_float
 
 # name -> argument ctypes (every entry point returns int); mirrors include/bff_hip.h one to one
 SIGNATURES = {
-    "bff_rle_to_maskbits": [_P, _P, _P, _P, _I, _L, _I, _P, _P],
-    "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P],
+    "bff_rle_to_maskbits": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P],
+    "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P],
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
     "bff_row_stats": [_P, _I, _L, _P, _P, _P, _P, _P, _P],
@@ -132,21 +132,26 @@ i32, i64, f32, f64, u8 = torch.int32, torch.int64, torch.float32, torch.float64,
 
 
 # ------------------------------------------------------------------ typed wrappers
-def rle_to_maskbits(run_start, run_end, mask_run_offs, view_mask_offs, n_views, n_pixels, word_bits, maskbits):
+def segmap_words(n_pixels):
+    return ((n_pixels + 127) // 128 + 31) // 32
+
+
+def rle_to_maskbits(run_start, run_end, mask_run_offs, view_mask_offs, n_views, n_pixels, word_bits, maskbits,
+                    segmap=None):
     call("bff_rle_to_maskbits", _ptr(run_start, i32), _ptr(run_end, i32), _ptr(mask_run_offs, i32),
          _ptr(view_mask_offs, i32), n_views, n_pixels, word_bits,
-         _ptr(maskbits, torch.int32 if word_bits == 32 else torch.int64))
+         _ptr(maskbits, torch.int32 if word_bits == 32 else torch.int64), _ptr(segmap, i32))
 
 
 def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, height, width, depth_thresh,
                   maskbits, word_bits, frame_mask, frame_rowbase, frame_nmask, frame_flags,
-                  rows, masked_count, viewed_count):
+                  rows, masked_count, viewed_count, segmap=None):
     k = (c_double * 9)(*[float(v) for v in cam_intr.reshape(-1)])
     n_frames = inv_pose.shape[0]
     nw = (n_points + 63) // 64
     call("bff_project_views", _ptr(xyz_soa, f64), n_points, xyz_soa.shape[1], _ptr(inv_pose, f64),
          ctypes.cast(k, c_void_p), n_frames, _ptr(depth, f32), _ptr(depth_index, i32), height, width,
-         float(depth_thresh), _ptr(maskbits), word_bits, _ptr(frame_mask, i32), _ptr(frame_rowbase, i32),
+         float(depth_thresh), _ptr(maskbits), _ptr(segmap, i32), word_bits, _ptr(frame_mask, i32), _ptr(frame_rowbase, i32),
          _ptr(frame_nmask, i32), _ptr(frame_flags, i32), _ptr(rows, i64),
          0 if rows is None else rows.shape[0], nw, _ptr(masked_count, i32), _ptr(viewed_count, i32))
 

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
     const double *__restrict__ xyz, int64_t n_points, int64_t n_pad,
     const double *__restrict__ inv_pose, Intrinsics K, int n_frames, int frames_per_block,
     const float *__restrict__ depth, const int32_t *__restrict__ depth_index, int H, int W, double thresh,
-    const WordT *__restrict__ maskbits, const int32_t *__restrict__ frame_mask,
+    const WordT *__restrict__ maskbits, const uint32_t *__restrict__ segmap, int64_t seg_words,
+    const int32_t *__restrict__ frame_mask,
     const int32_t *__restrict__ frame_rowbase, const int32_t *__restrict__ frame_nmask,
     const int32_t *__restrict__ frame_flags,
     uint64_t *__restrict__ rows, int64_t nw, int32_t *__restrict__ masked_count,
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
         const float *dimg = depth + (int64_t)depth_index[f] * hw;
         const int mi = maskbits ? frame_mask[f] : -1;
         const WordT *mimg = mi >= 0 ? maskbits + (int64_t)mi * hw : nullptr;
+        const uint32_t *smap = (segmap && mi >= 0) ? segmap + (int64_t)mi * seg_words : nullptr;
         const int nm = mimg ? frame_nmask[f] : 0;
         const bool count_viewed = (frame_flags[f] & 1) != 0;
 #pragma unroll
@@ -81,7 +83,11 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
                 const int64_t pix = (int64_t)(int)v * W + (int)u;
                 const float d = dimg[pix];
                 vis = (d != 0.0f) && (fabs(cz - (double)d) < thresh);
-                if (vis && mimg) w = mimg[pix];
+                if (vis && mimg) {
+                    // segments without any mask pixel were never written by the decoder: consult its bitmap
+                    const bool has = !smap || ((smap[pix >> 12] >> ((pix >> 7) & 31)) & 1);
+                    if (has) w = mimg[pix];
+                }
             }
             if (count_viewed) vcount[j] += vis ? 1 : 0;
             if (mimg) {
@@ -136,7 +142,7 @@ template <typename WordT>
 __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
     const int32_t *__restrict__ run_start, const int32_t *__restrict__ run_end,
     const int32_t *__restrict__ mask_run_offs, const int32_t *__restrict__ view_mask_offs,
-    int64_t n_pixels, WordT *__restrict__ maskbits)
+    int64_t n_pixels, WordT *__restrict__ maskbits, uint32_t *__restrict__ segmap, int64_t seg_words)
 {
     __shared__ WordT bits[kChunk];
     __shared__ WordT wave_tot[2][2 * kBlock / kWave];  // [parity][half * 4 + wave]; double buffered across chunks
@@ -216,8 +222,20 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
             const WordT carry = h ? carry1 : carry0;
             const int64_t p0 = c0 + h * kHalf + (int64_t)tid * kQ;
             WordT outv[kQ];
+            WordT any = 0;
 #pragma unroll
-            for (int k = 0; k < kQ; ++k) outv[k] = loc[h][k] ^ carry;
+            for (int k = 0; k < kQ; ++k) { outv[k] = loc[h][k] ^ carry; any |= outv[k]; }
+            if (segmap) {
+                // 128-pixel segments = 32 consecutive threads: all-zero segments are not stored at all, the
+                // sweep learns from the bitmap (one bit per segment) that there is nothing to gather there
+                const uint64_t nz = __ballot(any != 0);
+                const uint32_t half_nz = (uint32_t)(nz >> (lane & 32));
+                if ((lane & 31) == 0 && p0 < c1) {
+                    const int64_t seg = p0 >> 7;
+                    if (half_nz) atomicOr(segmap + (int64_t)v * seg_words + (seg >> 5), 1u << (seg & 31));
+                }
+                if (!half_nz) continue;
+            }
             if (p0 + kQ <= c1) {
                 const Vec *src = reinterpret_cast<const Vec *>(outv);
                 Vec *dst = reinterpret_cast<Vec *>(img + p0);      // chunk starts are multiples of 2048 words
@@ -238,7 +256,7 @@ using namespace bff;
 
 extern "C" int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const int32_t *mask_run_offs,
                                    const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels,
-                                   int32_t word_bits, void *maskbits, void *stream)
+                                   int32_t word_bits, void *maskbits, uint32_t *segmap, void *stream)
 {
     BFF_REQUIRE(n_views >= 0 && n_pixels > 0, "bff_rle_to_maskbits: bad sizes");
     BFF_REQUIRE(word_bits == 32 || word_bits == 64, "bff_rle_to_maskbits: word_bits must be 32 or 64");
@@ -246,12 +264,17 @@ extern "C" int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_
     if (n_views == 0) return BFF_OK;
     BFF_REQUIRE(mask_run_offs && view_mask_offs && maskbits, "bff_rle_to_maskbits: null pointer");   // run arrays may be empty (NULL)
     dim3 grid((unsigned)ceil_div(n_pixels, (int64_t)kChunk * kChunksPerBand), (unsigned)n_views);
+    const int64_t seg_words = ceil_div(ceil_div(n_pixels, 128), 32);
+    if (segmap) {
+        hipError_t e = hipMemsetAsync(segmap, 0, sizeof(uint32_t) * (size_t)n_views * seg_words, as_stream(stream));
+        if (e != hipSuccess) return fail((int)e, "bff_rle_to_maskbits: memset: %s", hipGetErrorString(e));
+    }
     if (word_bits == 32)
         rle_to_maskbits_kernel<uint32_t><<<grid, kBlock, 0, as_stream(stream)>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits);
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words);
     else
         rle_to_maskbits_kernel<uint64_t><<<grid, kBlock, 0, as_stream(stream)>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits);
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words);
     return launched("bff_rle_to_maskbits");
 }
 
@@ -259,7 +282,7 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
                                  const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
                                  const float *depth, const int32_t *depth_index, int32_t height, int32_t width,
                                  double depth_thresh,
-                                 const void *maskbits, int32_t word_bits,
+                                 const void *maskbits, const uint32_t *segmap, int32_t word_bits,
                                  const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
                                  const int32_t *frame_flags,
                                  uint64_t *rows, int64_t n_rows, int64_t nw,
@@ -281,15 +304,16 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
     int fpb = (int)((int64_t)n_frames * gx / 4096);      // keep >= ~4096 blocks in flight
     fpb = fpb < 1 ? 1 : (fpb > 8 ? 8 : fpb);
     dim3 grid((unsigned)gx, (unsigned)ceil_div(n_frames, fpb));
+    const int64_t seg_words = ceil_div(ceil_div((int64_t)height * width, 128), 32);
     if (!maskbits || word_bits == 32)
         project_views_kernel<uint32_t><<<grid, kBlock, 0, as_stream(stream)>>>(
             xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
-            (const uint32_t *)maskbits, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
+            (const uint32_t *)maskbits, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
             masked_count, viewed_count);
     else
         project_views_kernel<uint64_t><<<grid, kBlock, 0, as_stream(stream)>>>(
             xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
-            (const uint64_t *)maskbits, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
+            (const uint64_t *)maskbits, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
             masked_count, viewed_count);
     return launched("bff_project_views");
 }

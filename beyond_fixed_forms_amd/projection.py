@@ -174,9 +174,10 @@ def _run_projection(ds: DeviceScene, cfg, debug_out, timers, phases) -> Stage2Re
     n_mviews = ds.view_mask_offs.shape[0] - 1
     maskbits = torch.empty((n_mviews, ds.height * ds.width), device=dev,
                            dtype=torch.int32 if ds.word_bits == 32 else torch.int64)
+    segmap = torch.empty((n_mviews, _lib.segmap_words(ds.height * ds.width)), dtype=torch.int32, device=dev)
     with span(timers, "rle_to_maskbits"):
         _lib.rle_to_maskbits(ds.run_start, ds.run_end, ds.mask_run_offs, ds.view_mask_offs, n_mviews,
-                             ds.height * ds.width, ds.word_bits, maskbits)
+                             ds.height * ds.width, ds.word_bits, maskbits, segmap)
 
     # a2-a8 (+a15): one fused sweep over the frames (P:413-461 and P:538-567)
     rows = torch.empty((ds.n_rows, nw), dtype=torch.int64, device=dev)
@@ -187,7 +188,7 @@ def _run_projection(ds: DeviceScene, cfg, debug_out, timers, phases) -> Stage2Re
         _lib.project_views(ds.xyz, n, ds.inv_pose[:n_frames], ds.cam_intr, ds.depth, ds.depth_index, ds.height,
                            ds.width, DEPTH_THRESH, maskbits if n_mviews else None, ds.word_bits, ds.frame_mask,
                            ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows if ds.n_rows else None,
-                           masked, viewed)
+                           masked, viewed, segmap if n_mviews else None)
     del maskbits
     # a14/a15: point filter (P:512-583), entirely on the device: the threshold never visits the host
     if cfg.if_occurance_threshold or do_ratio:

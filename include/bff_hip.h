@@ -49,10 +49,13 @@ const char *bff_arch(void);
  * mask must be sorted and disjoint (what rle_encode_batch RLE:10-32 emits; the host normalises
  * anything else).  Output: maskbits[v][p] has bit b set iff pixel p lies in mask view_mask_offs[v]+b.
  * word_bits = 32 -> uint32 words, 64 -> uint64 words.
+ * segmap (optional): uint32 [n_views][ceil(ceil(n_pixels/128)/32)] bitmap, bit s of a view = "128-pixel
+ * segment s contains a mask pixel".  When given, all-zero segments of maskbits are NOT written (their
+ * content is undefined) and bff_project_views must be given the same bitmap; NULL = every word is written.
  */
 int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const int32_t *mask_run_offs,
                         const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels, int32_t word_bits,
-                        void *maskbits, void *stream);
+                        void *maskbits, uint32_t *segmap, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a2-a7 (+a15) -- fused per-frame: world->camera transform, projection, rounding, bounds +
@@ -66,6 +69,7 @@ int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const 
  *   inv_pose     float64 [n_frames][16] row-major inverse camera pose (np.linalg.inv on the host)
  *   cam_intr     float64 [9] row-major K (HOST pointer; copied into kernel arguments)
  *   depth        float32 [n_depth][H*W] metres; frame f uses image depth_index[f]
+ *   segmap       the decoder's segment bitmap (see bff_rle_to_maskbits) or NULL
  *   frame_mask   int32 [n_frames]: index of the frame's mask-word image in `maskbits`, or -1
  *   frame_rowbase int32 [n_frames]: first instance row of the frame (row = rowbase + bit)
  *   frame_nmask  int32 [n_frames]: number of masks (bits) of the frame, 0..word_bits
@@ -87,7 +91,7 @@ int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
                       const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
                       const float *depth, const int32_t *depth_index, int32_t height, int32_t width,
                       double depth_thresh,
-                      const void *maskbits, int32_t word_bits,
+                      const void *maskbits, const uint32_t *segmap, int32_t word_bits,
                       const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
                       const int32_t *frame_flags,
                       uint64_t *rows, int64_t n_rows, int64_t nw,

@@ -60,7 +60,7 @@ def test_checksums_and_layout_invariance(c2):
     zero_flags = torch.zeros_like(ds_plain.frame_flags)
     _lib.project_views(ds_plain.xyz, n, ds_plain.inv_pose, ds_plain.cam_intr, ds_plain.depth, ds_plain.depth_index,
                        ds_plain.height, ds_plain.width, 0.08, mb, 32, ds_plain.frame_mask, ds_plain.frame_rowbase,
-                       ds_plain.frame_nmask, zero_flags, rows_a, m_a, None)
+                       ds_plain.frame_nmask, zero_flags, rows_a, m_a, None)          # full images, no segment bitmap
     _lib.project_views(ds_plain.xyz, n, ds_plain.inv_pose, ds_plain.cam_intr, ds_plain.depth, ds_plain.depth_index,
                        ds_plain.height, ds_plain.width, 0.08, None, 32, ds_plain.frame_mask, ds_plain.frame_rowbase,
                        ds_plain.frame_nmask, torch.ones_like(zero_flags), None, None, v_a)

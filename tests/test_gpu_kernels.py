@@ -51,6 +51,18 @@ def maskbits_from_dense(lib, masks_list, hw):
     t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).to(DEV)
     out = torch.empty((len(masks_list), hw), dtype=torch.int32 if wb == 32 else torch.int64, device=DEV)
     lib.rle_to_maskbits(t(rs), t(re), t(offs), t(voffs), len(masks_list), hw, wb, out)
+    # with a segment bitmap the all-zero 128-pixel segments are skipped; what IS flagged must equal the full decode
+    out2 = torch.full_like(out, -1)
+    seg = torch.empty((len(masks_list), lib.segmap_words(hw)), dtype=torch.int32, device=DEV)
+    lib.rle_to_maskbits(t(rs), t(re), t(offs), t(voffs), len(masks_list), hw, wb, out2, seg)
+    bits = np.unpackbits(seg.cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[:, :(hw + 127) // 128].astype(bool)
+    full = out.cpu().numpy()
+    nz = np.stack([np.add.reduceat((full[v] != 0).astype(np.int64), np.arange(0, hw, 128)) > 0 for v in range(len(masks_list))])
+    assert np.array_equal(bits, nz)
+    per_px = np.repeat(bits, 128, axis=1)[:, :hw]
+    assert np.array_equal(out2.cpu().numpy()[per_px], full[per_px]) and (out2.cpu().numpy()[~per_px] == -1).all()
+    maskbits_from_dense.last_segmap = seg
+    maskbits_from_dense.last_sparse = out2
     return out, wb
 
 
@@ -104,9 +116,14 @@ def run_view(lib, xyz, inv_pose, k33, depth, masks):
     rows = torch.empty((m, nw), dtype=torch.int64, device=DEV)
     mc = torch.zeros(n, dtype=torch.int32, device=DEV)
     vc = torch.zeros(n, dtype=torch.int32, device=DEV)
-    lib.project_views(torch.from_numpy(soa).to(DEV), n, torch.from_numpy(inv_pose.reshape(1, 16).copy()).to(DEV), k33,
-                      torch.from_numpy(depth.reshape(1, -1).copy()).to(DEV), i32([0]), h, w, 0.08, bits, wb,
-                      i32([0]), i32([0]), i32([m]), i32([1]), rows, mc, vc)
+    args = (torch.from_numpy(soa).to(DEV), n, torch.from_numpy(inv_pose.reshape(1, 16).copy()).to(DEV), k33,
+            torch.from_numpy(depth.reshape(1, -1).copy()).to(DEV), i32([0]), h, w, 0.08)
+    lib.project_views(*args, bits, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows, mc, vc)
+    # same sweep over the sparsely written image + segment bitmap
+    rows2, mc2, vc2 = torch.empty_like(rows), torch.zeros_like(mc), torch.zeros_like(vc)
+    lib.project_views(*args, maskbits_from_dense.last_sparse, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows2, mc2, vc2,
+                      segmap=maskbits_from_dense.last_segmap)
+    assert torch.equal(rows2, rows) and torch.equal(mc2, mc) and torch.equal(vc2, vc)
     return unpack(rows, n), mc.cpu().numpy(), vc.cpu().numpy()
 
 

@@ -35,7 +35,7 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.bff_popcount_rows(None, None, -1, 0, None, None) == -1
     assert b"bad sizes" in lib.bff_last_error()
     assert lib.bff_cosine_gemm_f16(None, 1, None, 1, 33, None, None) == -1
-    assert lib.bff_rle_to_maskbits(None, None, None, None, 1, 10, 48, None, None) == -1
+    assert lib.bff_rle_to_maskbits(None, None, None, None, 1, 10, 48, None, None, None) == -1
     assert lib.bff_popcount_rows(None, None, 0, 0, None, None) == 0          # empty work is fine
 
 
