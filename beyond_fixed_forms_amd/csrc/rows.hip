@@ -159,40 +159,53 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restri
     }
 }
 
-// tmask[t] = OR of the chunk masks of the 64 rows order[64t .. 64t+63]
-__global__ void tile_masks_kernel(const uint64_t *__restrict__ cmask, const int32_t *__restrict__ order, int n,
-                                  int mw, uint64_t *__restrict__ tmask, const uint32_t *__restrict__ hist,
-                                  uint32_t *__restrict__ hist_sorted, int n_pos, const int32_t *__restrict__ area,
-                                  uint32_t *__restrict__ tile_hmax, int32_t *__restrict__ tile_amin)
+// Per tile t (rows order[64t .. 64t+63]): tmask[t] = OR of the rows' chunk masks; optionally the sorted,
+// packed histogram copy hist_sorted[bin pair][position] (two 16-bit bins per word: coalesced tile loads, one
+// v_pk_min_u16 + v_dot2_u32_u16 per two bins), the bin-wise maxima and the smallest non-empty area of the tile.
+// 256 threads: thread (k = tid & 63, q = tid >> 6) works on row k of the tile.
+__global__ __launch_bounds__(256) void tile_masks_kernel(const uint64_t *__restrict__ cmask,
+                                                          const int32_t *__restrict__ order, int n, int mw,
+                                                          uint64_t *__restrict__ tmask, const uint32_t *__restrict__ hist,
+                                                          uint32_t *__restrict__ hist_sorted, int n_pos,
+                                                          const int32_t *__restrict__ area,
+                                                          uint32_t *__restrict__ tile_hmax, int32_t *__restrict__ tile_amin)
 {
-    const int t = blockIdx.x;
-    if (hist_sorted) {                                   // hist_sorted[bin][position]: coalesced tile loads
-        const int pos = t * kT + threadIdx.x;
-        const int r = pos < n ? (order ? order[pos] : pos) : -1;
-        for (int b = 0; b < kBins; ++b) hist_sorted[(int64_t)b * n_pos + pos] = r >= 0 ? hist[(int64_t)r * kBins + b] : 0;
-        // per tile: bin-wise maximum over its rows and the smallest non-empty area (tile-level edge bound)
-        uint32_t hm = 0;
-        int amin = 0x7fffffff;
-        for (int k = 0; k < kT; ++k) {
-            const int rr = t * kT + k;
-            if (rr < n) {
-                const int row = order ? order[rr] : rr;
-                hm = max(hm, hist[(int64_t)row * kBins + threadIdx.x]);
-                const int a = area[row];
-                if (a > 0) amin = min(amin, a);
-            }
-        }
-        tile_hmax[(int64_t)t * kBins + threadIdx.x] = hm;
-        if (threadIdx.x == 0) tile_amin[t] = amin;
+    __shared__ uint32_t s_hmax[kBins];
+    __shared__ int s_amin;
+    const int t = blockIdx.x, tid = threadIdx.x, k = tid & 63, q = tid >> 6;
+    const int pos = t * kT + k;
+    const int row = pos < n ? (order ? order[pos] : pos) : -1;
+    // chunk-mask OR: lanes = rows, each wave takes every 4th mask word and OR-reduces it across the wave
+    for (int i = q; i < mw; i += 4) {
+        uint64_t v = row >= 0 ? cmask[(int64_t)row * mw + i] : 0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d);
+        if (k == 0) tmask[(int64_t)t * mw + i] = v;
     }
-    for (int i = threadIdx.x; i < mw; i += blockDim.x) {
-        uint64_t v = 0;
-        for (int k = 0; k < kT; ++k) {
-            const int r = t * kT + k;
-            if (r < n) v |= cmask[(int64_t)(order ? order[r] : r) * mw + i];
-        }
-        tmask[(int64_t)t * mw + i] = v;
+    if (!hist_sorted) return;
+    if (tid < kBins) s_hmax[tid] = 0;
+    if (tid == 0) s_amin = 0x7fffffff;
+    __syncthreads();
+    // wave q handles bin pairs q, q+4, ...: row k's two bins -> packed word, tile maxima via LDS atomics
+    for (int b = q; b < kBins / 2; b += 4) {
+        const uint32_t lo = row >= 0 ? hist[(int64_t)row * kBins + 2 * b] : 0;
+        const uint32_t hi = row >= 0 ? hist[(int64_t)row * kBins + 2 * b + 1] : 0;
+        hist_sorted[(int64_t)b * n_pos + pos] = lo | (hi << 16);
+        uint32_t mlo = lo, mhi = hi;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { mlo = max(mlo, (uint32_t)__shfl_xor(mlo, d)); mhi = max(mhi, (uint32_t)__shfl_xor(mhi, d)); }
+        if (k == 0) { s_hmax[2 * b] = mlo; s_hmax[2 * b + 1] = mhi; }
     }
+    if (q == 0) {
+        int a = row >= 0 ? area[row] : 0;
+        a = a > 0 ? a : 0x7fffffff;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) a = min(a, __shfl_xor(a, d));
+        if (k == 0) s_amin = a;
+    }
+    __syncthreads();
+    if (tid < kBins) tile_hmax[(int64_t)t * kBins + tid] = s_hmax[tid];
+    if (tid == 0) tile_amin[t] = s_amin;
 }
 
 // Upper-triangular tile pairs of the symmetric Gram matrix.  Tile (bi, bj) covers rows
@@ -414,7 +427,7 @@ __global__ void uf_flatten_kernel(int32_t *parent, int n, int32_t *comp)
 
 // Skeleton pass: one wave per pair of rows `stride` apart in the sorted order.  Rows with the same signature
 // show the same object, so a handful of strides links most of every large component before the tile pass
-// starts, which then finds the bulk of its possible edges already connected.  Exact test, same as the tiles.
+// starts, which then finds many of its possible edges already connected.  Exact test, same as the tiles.
 __global__ __launch_bounds__(256) void uf_skeleton_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
                                                            const int32_t *__restrict__ order,
                                                            const uint64_t *__restrict__ cmask, int mw,
@@ -511,33 +524,40 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
         rowB[tid - kT] = r < n ? (order ? order[r] : r) : -1;
         rootB[tid - kT] = rowB[tid - kT] >= 0 ? uf_find(parent, rowB[tid - kT]) : -2;
     }
-    // histogram bound (see merge_adjacency_kernel): possible edges only
-    uint32_t (*ha)[kBins] = reinterpret_cast<uint32_t (*)[kBins]>(&sa[0][0]);
-    uint32_t (*hb)[kBins] = reinterpret_cast<uint32_t (*)[kBins]>(&sb[0][0]);
+    // histogram bound (see merge_adjacency_kernel): possible edges only.  hist holds two 16-bit bins per
+    // word, so one v_pk_min_u16 + one v_dot2_u32_u16 accumulates two bins of sum_b min(hist_i, hist_j).
+    constexpr int kBP = kBins / 2;
+    uint32_t (*ha)[kT] = reinterpret_cast<uint32_t (*)[kT]>(&sa[0][0]);      // [bin pair][row], 8 KB each
+    uint32_t (*hb)[kT] = reinterpret_cast<uint32_t (*)[kT]>(&sb[0][0]);
     {
-        const int lane = tid & 63, wv = tid >> 6;          // hist is [bin][position]: 256-B coalesced rows
+        const int lane = tid & 63, wv = tid >> 6;          // 256-B coalesced rows of the sorted histogram
 #pragma unroll
-        for (int q = 0; q < kBins / 4; ++q) {
-            const int b = wv * (kBins / 4) + q;
+        for (int q = 0; q < kBP / 4; ++q) {
+            const int b = wv * (kBP / 4) + q;
             ha[b][lane] = hist[(int64_t)b * n_pos + i0 + lane];
             hb[b][lane] = hist[(int64_t)b * n_pos + j0 + lane];
         }
     }
     __syncthreads();
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     uint32_t ub[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) ub[r][c] = 0;
+    const us2 ones = {1, 1};
 #pragma unroll 4
-    for (int b = 0; b < kBins; ++b) {
+    for (int b = 0; b < kBP; ++b) {
         uint32_t av[4], bv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { av[r] = ha[b][ti * 4 + r]; bv[r] = hb[b][tj * 4 + r]; }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ub[r][c] += min(av[r], bv[c]);
+            for (int c = 0; c < 4; ++c) {
+                const us2 m = __builtin_elementwise_min(__builtin_bit_cast(us2, av[r]), __builtin_bit_cast(us2, bv[c]));
+                ub[r][c] = __builtin_amdgcn_udot2(m, ones, ub[r][c], false);
+            }
     }
     unsigned cand = 0;                                             // bit 4r+c: pair still needs the exact test
 #pragma unroll
@@ -995,7 +1015,7 @@ extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t
     const int mw = (int)ceil_div(n_chunks, 64);
     // pairs with an empty intersection have IoU 0 (or NaN): they can only be skipped when 0 > thr is false
     const bool sparse = chunk_mask && !(0.0f > iou_thres);
-    if (sparse) tile_masks_kernel<<<nt, 64, 0, as_stream(stream)>>>(chunk_mask, order, n_rows, mw, tile_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+    if (sparse) tile_masks_kernel<<<nt, 256, 0, as_stream(stream)>>>(chunk_mask, order, n_rows, mw, tile_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
     const int aw = nt;   // ceil(n_rows/64) words per adjacency row
     merge_adjacency_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, as_stream(stream)>>>(
         rows, n_rows, nw, order, sparse ? tile_mask : nullptr, mw, (sparse && !inter) ? hist : nullptr, area, label_id,
@@ -1026,9 +1046,9 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
         // scratch carved from hist_sorted: [64][nt*64] sorted histograms, then [nt][64] tile maxima, then [nt] min areas
         uint32_t *tile_hmax = hist_sorted + (size_t)kBins * nt * kT;
         int32_t *tile_amin = reinterpret_cast<int32_t *>(tile_hmax + (size_t)nt * kBins);
-        tile_masks_kernel<<<nt, 64, 0, st>>>(chunk_mask, order, n_order, mw, tile_mask, hist, hist_sorted, nt * kT, area,
+        tile_masks_kernel<<<nt, 256, 0, st>>>(chunk_mask, order, n_order, mw, tile_mask, hist, hist_sorted, nt * kT, area,
                                              tile_hmax, tile_amin);
-        constexpr int kStrides = 8;                                    // 1, 2, 3, 5, 8, 13, 21, 29
+        constexpr int kStrides = 4;                                    // 1, 2, 3, 5 (more strides measured no faster)
         dim3 sgrid((unsigned)ceil_div(n_order, 4), kStrides);
         uf_skeleton_kernel<<<sgrid, 256, 0, st>>>(rows, n_order, nw, order, chunk_mask, mw, area, label_id, iou_thres,
                                                   parent, kStrides);
