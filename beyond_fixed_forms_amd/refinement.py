@@ -133,13 +133,14 @@ def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: Text
         other = [i for i, lab in enumerate(s1_labels) if lab == query_us]
         return _SceneState(scene_id, n, [], [], None, None, [], _lib.gather_rows(s1, i32(other)) if other else s1[:0])
 
-    area1, area2, inter = (torch.from_numpy(a) for a in
-                           _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2), _lib.cross_popcount(s1, s2)))
+    # one read-back for everything pass 1 needs from the device: areas, stage-1 x stage-2 intersections, and
+    # the stage-1 x stage-1 intersections (so the duplicate test R:217 needs no second round trip)
+    area1, area2, inter, inter11 = (torch.from_numpy(a) for a in
+                                    _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2),
+                                               _lib.cross_popcount(s1, s2), _lib.cross_popcount(s1, s1)))
     iou = _iou(inter, area1, area2)                                                 # R:208  (K, S1)
     best = torch.argmax(iou, dim=1)                                                 # R:211
-    b32 = best.to(torch.int32).to(device)
-    m_inter = torch.from_numpy(_lib.fetch(_lib.cross_popcount(s1, s1, b32, b32))[0])
-    m_iou = _iou(m_inter, area1[best], area1[best])                                 # R:217
+    m_iou = _iou(inter11[best][:, best], area1[best], area1[best])                  # R:217
     k = len(best)
     m_iou[range(k), range(k)] = 0                                                   # R:221
     m_adj = (m_iou > cfg.stage1_iou_thres).to(int)                                  # R:224
@@ -172,16 +173,18 @@ def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: Text
             parts = [part for keep, part in zip(sel.tolist(), parts) if not keep] + [merged]
             conf2 = torch.cat([conf2[~sel], mconf.unsqueeze(0)])
             chosen_t = torch.cat([chosen_t[~sel], u.unsqueeze(0)])
-    if any(len(p) > 1 for p in parts) or len(parts) != k:
+    regrouped = any(len(p) > 1 for p in parts) or len(parts) != k
+    if regrouped:
         offs = np.zeros(len(parts) + 1, dtype=np.int32)
         np.cumsum([len(p) for p in parts], out=offs[1:])
         s2 = _lib.or_reduce_groups(s2, torch.from_numpy(offs).to(device),
                                    i32([p for part in parts for p in part]), max(len(p) for p in parts))
 
-    area1, area2, inter = (torch.from_numpy(a) for a in                              # stage-1 rows may have grown
-                           _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2), _lib.cross_popcount(s1, s2)))
-    iou = _iou(inter, area1, area2)                                                 # R:285
-    best = torch.argmax(iou, dim=1)                                                 # R:288
+    if ops or regrouped:            # rows changed: recompute R:285-288; otherwise iou / best are what they were
+        area1, area2, inter = (torch.from_numpy(a) for a in
+                               _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2), _lib.cross_popcount(s1, s2)))
+        iou = _iou(inter, area1, area2)                                             # R:285
+        best = torch.argmax(iou, dim=1)                                             # R:288
     best_l = best.tolist()
     other = [i for i, lab in enumerate(s1_labels) if lab == query_us and i not in best_l]   # R:293
     labels = [s1_labels[i] for i in best_l]                                         # R:297

@@ -151,6 +151,42 @@ def test_scene_vs_oracle(api, case, mode):
     same(fin[scene.scene_id].to_dict(), fexp[scene.scene_id])
 
 
+@pytest.mark.parametrize("variant", ["dup_stage1_and_shared_match", "nothing_merges", "only_shared_match"])
+def test_refinement_merge_branches(api, variant):
+    """Crafted stage-1 / stage-2 masks drive both order-dependent branches of R:211-281: matched stage-1 masks
+    that overlap (IoU > 0.1) are OR-ed in place, stage-2 masks matched to the same stage-1 mask are merged
+    (any / mean).  Final results identical to the oracle, also when nothing merges (no recomputation)."""
+    _, refinement = api
+    from beyond_fixed_forms_amd.labels import SCANNET200_LABELS
+    from beyond_fixed_forms_amd.synthetic import make_text_bank
+    from oracle.rle_ref import rle_encode_batch_ref
+    n = 1000
+    def m(*ranges):
+        r = np.zeros(n, bool)
+        for a, b in ranges:
+            r[a:b] = True
+        return r
+    s1 = [m((0, 100)), m((10, 110)), m((200, 300)), m((400, 450)), m((700, 720)), m((440, 500))]
+    if variant == "dup_stage1_and_shared_match":
+        s2 = [m((0, 90)), m((15, 110)), m((200, 290)), m((210, 300)), m((600, 650)), m((405, 452))]
+    elif variant == "only_shared_match":
+        s2 = [m((200, 290)), m((210, 300)), m((405, 440))]
+    else:
+        s2 = [m((0, 90)), m((205, 300)), m((700, 715))]
+    q = SCANNET200_LABELS.index("table")
+    stage1 = {"ins": rle_encode_batch_ref(torch.from_numpy(np.stack(s1))), "conf": torch.ones(len(s1)),
+              "final_class": [q, 3, q, 7, q, q]}
+    conf = torch.tensor([0.31, 0.22, 0.43, 0.27, 0.39, 0.25][:len(s2)], dtype=torch.float16)
+    stage2 = {"ins": torch.from_numpy(np.stack(s2)), "conf": conf, "final_class": ["table"] * len(s2)}
+    bank, index = make_text_bank(64, seed=2)
+    enc = bank_encoder(bank.float(), index)
+    cfg = cfg_for(type("S", (), {"width": 8, "height": 8}))
+    exp = rref.refine_class_ref([("s_00", stage1, {k: (v.clone() if torch.is_tensor(v) else list(v)) for k, v in stage2.items()})],
+                                cfg, "table", enc)
+    got = refinement.refine_class([("s_00", stage1, stage2)], cfg, "table", refinement.TextSimilarity(enc, DEV), DEV)
+    same(got["s_00"].to_dict(), exp["s_00"])
+
+
 def test_empty_inputs(api):
     """No 2-D masks at all (P:465-478) and nothing merged (P:496-509): the reference's empty form."""
     projection, refinement = api
