@@ -46,7 +46,8 @@ SIGNATURES = {
     "bff_cosine_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
 }
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
-         "bff_chunk_mask_words": (c_int32, [c_int64])}
+         "bff_chunk_mask_words": (c_int32, [c_int64]),
+         "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P])}
 ABI_VERSION = 1
 
 
@@ -352,6 +353,24 @@ def point_threshold(masked, viewed, fraction):
 
 
 _pinned = {}
+
+
+def host_component_csr(comp, has_self_loop, min_members):
+    """numpy in, numpy out: (offs int32 [K+1], members int32, sizes int32 [K], n_void) or None if an id is out
+    of range (caller falls back to the NumPy implementation)."""
+    import numpy as np
+    n = comp.shape[0]
+    comp = np.ascontiguousarray(comp, dtype=np.int32)
+    sl = np.ascontiguousarray(has_self_loop, dtype=np.uint8)
+    offs = np.empty(n + 1, dtype=np.int32)
+    members = np.empty(max(n, 1), dtype=np.int32)
+    sizes = np.empty(max(n, 1), dtype=np.int32)
+    n_void = c_int32(0)
+    p = lambda a: a.ctypes.data_as(c_void_p)
+    k = load().bff_host_component_csr(p(comp), p(sl), n, int(min_members), p(offs), p(members), p(sizes), ctypes.byref(n_void))
+    if k < 0:
+        return None
+    return offs[:k + 1], members[:offs[k]], sizes[:k], int(n_void.value)
 
 
 def fetch(*tensors):

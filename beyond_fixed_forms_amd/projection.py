@@ -228,7 +228,8 @@ def _run_projection(ds: DeviceScene, cfg, debug_out, timers, phases) -> Stage2Re
             dbg["viewed_counts"] = back(viewed)
     mark("stats+components")
     self_loop = (area_h > 0) & bool(np.float32(1.0) > np.float32(cfg.iou_thres))
-    offs, members, sizes, n_void = component_csr(comp_h, self_loop, cfg.min_aggragated_masks)     # P:203
+    csr = _lib.host_component_csr(comp_h, self_loop, cfg.min_aggragated_masks)                    # P:203
+    offs, members, sizes, n_void = csr if csr is not None else component_csr(comp_h, self_loop, cfg.min_aggragated_masks)
     if n_void:      # min_aggragated_masks <= 0 keeps empty components in the size list (P:285): exact, slower path
         groups = groups_from_labels(comp_h, self_loop, cfg.min_aggragated_masks)
         size_list = [len(g) for g in groups]

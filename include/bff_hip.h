@@ -38,6 +38,14 @@ const char *bff_last_error(void);
 /* gfx target the library was compiled for ("gfx950"). */
 const char *bff_arch(void);
 
+/* Host-side helper (plain CPU code, all pointers are HOST pointers, no stream): component ids -> the groups
+ * merge_masks keeps (P:203-226) as CSR.  comp[i] in [0, n) names the component of row i (e.g. the output of
+ * bff_merge_components); kept: components with >= max(min_members, 1) members except isolated rows without
+ * a self loop (the reference's `[]`, counted in *n_void when min_members <= 0); order: by smallest member,
+ * members ascending.  Returns K (offs[0..K], members[0..offs[K]), sizes[0..K)); -1 = id out of range. */
+int bff_host_component_csr(const int32_t *comp, const uint8_t *has_self_loop, int32_t n, int32_t min_members,
+                           int32_t *offs, int32_t *members, int32_t *sizes, int32_t *n_void);
+
 /* ------------------------------------------------------------------------------------------
  * a1 -- 2-D RLE masks -> per-pixel mask words.   Replaces RLE.rle_decode_batch (RLE:35-61) +
  * decode_2d_masks (RLE:82-99) + the float conversion at P:417-421; the dense (M,1,H,W) uint8

@@ -94,6 +94,11 @@ def test_groups_from_labels_matches_closure_components():
             assert [members[offs[g]:offs[g + 1]].tolist() for g in range(len(sizes))] == want
             assert sizes.tolist() == [len(g) for g in want]
             assert n_void == (sum(1 for g in exp if g == []) if mm <= 0 else 0)
+            from beyond_fixed_forms_amd import _lib
+            o2, m2, s2, v2 = _lib.host_component_csr(label.astype(np.int32), alive, mm)      # native twin
+            assert np.array_equal(o2, offs) and np.array_equal(m2, members) and np.array_equal(s2, sizes) and v2 == n_void
+    from beyond_fixed_forms_amd import _lib
+    assert _lib.host_component_csr(np.array([0, 5], np.int32), np.ones(2, bool), 1) is None     # id out of range
     # a node without a self loop that has a neighbour is a normal member (iou_thres < 0 with an empty mask)
     a = np.array([[1, 1, 0], [1, 0, 0], [0, 0, 0]], bool)
     assert pref.connected_groups(torch.from_numpy(a).float()) == [[0, 1], []]
