@@ -1,6 +1,6 @@
 """Condense rocprofv3 CSV output (kernel stats + PMC counter collection) into small per-kernel tables.
 
-usage: python tools/prof_summarize.py <rocprof_out_dir> <summary_out_dir> [name_filter=bff]
+usage: python scripts/prof_summarize.py <rocprof_out_dir> <summary_out_dir> [name_filter=bff]
 Keeps: header lines, every kernel whose name contains the filter, and the 12 heaviest other kernels.
 """
 import csv
