@@ -44,6 +44,7 @@ SIGNATURES = {
     "bff_point_values": [_P, _P, _L, _P, _P],
     "bff_select_unique_rank": [_P, _L, _D, _P, _P, _P, _P],
     "bff_cosine_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
+    "bff_depth_from_u16": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P],
 }
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
          "bff_chunk_mask_words": (c_int32, [c_int64]),
@@ -399,6 +400,17 @@ def ratio_keep(masked, viewed, thr, use_thr):
     call("bff_ratio_keep", _ptr(masked, i32), _ptr(viewed, i32), n, 0.0 if thr_dev is not None else float(thr),
          _ptr(thr_dev, f32), int(bool(use_thr)), nw, _ptr(keep))
     return keep
+
+
+def depth_from_u16(raw, height, width, taps=None, depth_scale=1000.0):
+    """uint16-as-int16 device tensor [F][h][w] (raw millimetres) -> float32 [F][height*width] metres, resized on
+    the device.  taps: (x0, x1, ax, y0, y1, ay) device tensors from io.bilinear_taps (None if sizes are equal)."""
+    f, hs, ws = raw.shape
+    out = torch.empty((f, height * width), dtype=f32, device=raw.device)
+    t = taps if taps is not None else (None,) * 6
+    call("bff_depth_from_u16", _ptr(raw, torch.int16), f, hs, ws, _ptr(t[0], i32), _ptr(t[1], i32), _ptr(t[2], f32),
+         _ptr(t[3], i32), _ptr(t[4], i32), _ptr(t[5], f32), height, width, float(depth_scale), _ptr(out))
+    return out
 
 
 def cosine_gemm_f16(a, b):

@@ -33,7 +33,8 @@ def projection_main(argv=None):
     for name in sorted(s for s in os.listdir(seg_dir) if s.endswith("_00.pth")):           # P:363
         scene_id = name[:-4]
         print("Working on", scene_id, "class", cls)
-        scene = load_scene(cfg, cls, scene_id)
+        # BFF_DEPTH_ON_DEVICE=1: upload the 16-bit depth PNGs as they are, scale + resize them on the GPU
+        scene = load_scene(cfg, cls, scene_id, depth_on_device=os.environ.get("BFF_DEPTH_ON_DEVICE") == "1")
         res = project_scene(scene, cfg, device="cuda", return_result=True)
         if not res.debug.get("empty_form", False):
             ckpt[scene_id] = True                                                         # P:580-581

@@ -108,6 +108,39 @@ __global__ void ratio_keep_kernel(const int32_t *__restrict__ masked, const int3
     if (lane_id() == 0 && (i >> 6) < nw) keep[i >> 6] = bal;
 }
 
+// ---- depth ingestion ------------------------------------------------------
+// raw 16-bit depth (millimetres, source resolution) -> float32 metres at (H, W): `png.astype(f32) / 1000`
+// followed by the 2-tap horizontal then vertical passes of a bilinear resize with half-pixel centres and
+// edge clamp (reference P:432-436 does this with cv2.imread + cv2.resize; restated on the host in
+// io.resize_bilinear_f32, to which this kernel is bit-identical: same float32 operation order, tap tables
+// computed by the host in float64).  One thread per output pixel; the 4 source texels are L2-resident.
+__global__ void depth_resize_kernel(const uint16_t *__restrict__ src, int hs, int ws, int n_frames,
+                                    const int32_t *__restrict__ x0, const int32_t *__restrict__ x1,
+                                    const float *__restrict__ ax, const int32_t *__restrict__ y0,
+                                    const int32_t *__restrict__ y1, const float *__restrict__ ay, int H, int W,
+                                    float scale, float *__restrict__ dst)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const uint16_t *img = src + (int64_t)f * hs * ws;
+    const float a = ax[x], b = ay[y];
+    const float one_a = __fsub_rn(1.0f, a), one_b = __fsub_rn(1.0f, b);
+    const int xa = x0[x], xb = x1[x];
+    auto tap = [&](int yy) {
+        const float s0 = __fdiv_rn((float)img[(int64_t)yy * ws + xa], scale);
+        const float s1 = __fdiv_rn((float)img[(int64_t)yy * ws + xb], scale);
+        return __fadd_rn(__fmul_rn(s0, one_a), __fmul_rn(s1, a));
+    };
+    const float r0 = tap(y0[y]), r1 = tap(y1[y]);
+    dst[((int64_t)f * H + y) * W + x] = __fadd_rn(__fmul_rn(r0, one_b), __fmul_rn(r1, b));
+}
+
+__global__ void depth_scale_kernel(const uint16_t *__restrict__ src, int64_t n, float scale, float *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = __fdiv_rn((float)src[i], scale);
+}
+
 }  // namespace bff
 
 using namespace bff;
@@ -139,4 +172,26 @@ extern "C" int bff_ratio_keep(const int32_t *masked, const int32_t *viewed, int6
     BFF_REQUIRE(masked && keep, "bff_ratio_keep: null pointer");
     ratio_keep_kernel<<<(unsigned)ceil_div(nw * 64, 256), 256, 0, as_stream(stream)>>>(masked, viewed, n_points, thr, thr_dev, use_thr, nw, keep);
     return launched("bff_ratio_keep");
+}
+
+extern "C" int bff_depth_from_u16(const uint16_t *src, int32_t n_frames, int32_t h_src, int32_t w_src,
+                                  const int32_t *x0, const int32_t *x1, const float *ax,
+                                  const int32_t *y0, const int32_t *y1, const float *ay,
+                                  int32_t height, int32_t width, float depth_scale, float *dst, void *stream)
+{
+    BFF_REQUIRE(n_frames >= 0 && h_src > 0 && w_src > 0 && height > 0 && width > 0 && depth_scale > 0,
+                "bff_depth_from_u16: bad sizes");
+    if (n_frames == 0) return BFF_OK;
+    BFF_REQUIRE(src && dst, "bff_depth_from_u16: null pointer");
+    if (h_src == height && w_src == width) {       // cv2.resize to the same size is the identity
+        const int64_t n = (int64_t)n_frames * height * width;
+        depth_scale_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, as_stream(stream)>>>(src, n, depth_scale, dst);
+        return launched("bff_depth_from_u16");
+    }
+    BFF_REQUIRE(x0 && x1 && ax && y0 && y1 && ay, "bff_depth_from_u16: tap tables required when resizing");
+    BFF_LIMIT(height <= 65535 && n_frames <= 65535, "bff_depth_from_u16: grid limits");
+    dim3 grid((unsigned)ceil_div(width, 256), (unsigned)height, (unsigned)n_frames);
+    depth_resize_kernel<<<grid, 256, 0, as_stream(stream)>>>(src, h_src, w_src, n_frames, x0, x1, ax, y0, y1, ay, height,
+                                                             width, depth_scale, dst);
+    return launched("bff_depth_from_u16");
 }

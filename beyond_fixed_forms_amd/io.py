@@ -19,6 +19,23 @@ from .synthetic import SceneInputs
 DEPTH_SCALE = 1000            # hard-coded at P:346
 
 
+def _axis_taps(n_dst, n_src):
+    f = (np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5
+    i0 = np.floor(f).astype(np.int64)
+    a = (f - i0).astype(np.float32)
+    a[i0 < 0] = 0.0
+    i0 = np.clip(i0, 0, n_src - 1)
+    i1 = np.clip(i0 + 1, 0, n_src - 1)
+    return i0, i1, a
+
+
+def bilinear_taps(h_src, w_src, height, width):
+    """Tap tables of the bilinear resize (x0, x1, ax, y0, y1, ay) as int32 / float32 arrays."""
+    x0, x1, ax = _axis_taps(width, w_src)
+    y0, y1, ay = _axis_taps(height, h_src)
+    return (x0.astype(np.int32), x1.astype(np.int32), ax, y0.astype(np.int32), y1.astype(np.int32), ay)
+
+
 def resize_bilinear_f32(img: np.ndarray, width: int, height: int) -> np.ndarray:
     """cv2.resize(img, (width, height)) with INTER_LINEAR for float32 input: half-pixel centres,
     edge clamp, horizontal then vertical 2-tap passes in float32."""
@@ -26,18 +43,7 @@ def resize_bilinear_f32(img: np.ndarray, width: int, height: int) -> np.ndarray:
     if (h, w) == (height, width):
         return img.copy()
     img = img.astype(np.float32, copy=False)
-
-    def taps(n_dst, n_src):
-        f = (np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5
-        i0 = np.floor(f).astype(np.int64)
-        a = (f - i0).astype(np.float32)
-        a[i0 < 0] = 0.0
-        i0 = np.clip(i0, 0, n_src - 1)
-        i1 = np.clip(i0 + 1, 0, n_src - 1)
-        return i0, i1, a
-
-    x0, x1, ax = taps(width, w)
-    y0, y1, ay = taps(height, h)
+    x0, x1, ax, y0, y1, ay = bilinear_taps(h, w, height, width)
     rows = img[:, x0] * (np.float32(1) - ax) + img[:, x1] * ax
     return rows[y0] * (np.float32(1) - ay)[:, None] + rows[y1] * ay[:, None]
 
@@ -54,8 +60,19 @@ def load_depth(path: str, width: int, height: int) -> np.ndarray:
         return resize_bilinear_f32(d, width, height)
 
 
-def load_scene(cfg, cls: str, scene_id: str) -> SceneInputs:
-    """Everything P:370-400 + the per-frame files of P:422-436 and P:526-563 for one scene."""
+def load_depth_raw(path: str) -> np.ndarray:
+    """The 16-bit PNG as stored (uint16 millimetres); scaling and resizing happen on the device."""
+    from PIL import Image
+    d = np.asarray(Image.open(path))
+    if d.dtype != np.uint16:
+        raise ValueError(f"{path}: expected a 16-bit depth PNG, got {d.dtype}")
+    return d
+
+
+def load_scene(cfg, cls: str, scene_id: str, depth_on_device: bool = False) -> SceneInputs:
+    """Everything P:370-400 + the per-frame files of P:422-436 and P:526-563 for one scene.
+    depth_on_device: keep the depth frames as raw uint16 (`SceneInputs.depths_raw`); prepare_scene uploads them
+    as they are and does /1000 + resize with bff_depth_from_u16."""
     scene_dir = os.path.join(cfg.scene_2d_dir, scene_id)
     cam_intr = np.loadtxt(os.path.join(scene_dir, "intrinsic", "intrinsic_color.txt"))          # P:376
     points = np.load(os.path.join(cfg.scene_npy_dir, f"{scene_id}.npy"))                         # P:387
@@ -70,6 +87,10 @@ def load_scene(cfg, cls: str, scene_id: str) -> SceneInputs:
         need |= set(viewed_frame_ids(color_files, cfg.downsample_ratio))
     w, h = int(cfg.width_2d), int(cfg.height_2d)
     poses = {f: np.loadtxt(os.path.join(scene_dir, "pose", f"{f}.txt")) for f in need}           # P:422
+    if depth_on_device:
+        raw = {f: load_depth_raw(os.path.join(scene_dir, "depth", f"{f}.png")) for f in need}
+        return SceneInputs(scene_id=scene_id, points=points, cam_intr=cam_intr, poses=poses, depths={}, depths_raw=raw,
+                           mask_2d=mask_2d, color_files=color_files, height=h, width=w)
     depths = {f: load_depth(os.path.join(scene_dir, "depth", f"{f}.png"), w, h) for f in need}   # P:431-436
     return SceneInputs(scene_id=scene_id, points=points, cam_intr=cam_intr, poses=poses, depths=depths,
                        mask_2d=mask_2d, color_files=color_files, height=h, width=w)

@@ -147,14 +147,21 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True)
     viewed = viewed_frame_ids(scene.color_files, cfg.downsample_ratio) if with_viewed else []
     viewed_left = dict.fromkeys(viewed)              # ordered set of frames still to be counted
     depth_slot, depth_list = {}, []
+    raw_depth = getattr(scene, "depths_raw", None)
 
     def slot(fid):
         if fid not in depth_slot:
-            d = np.asarray(scene.depths[fid], dtype=np.float32)
-            if d.shape != (h, w):
-                raise ValueError(f"depth {fid}: shape {d.shape} != ({h},{w})")
-            depth_slot[fid] = len(depth_list)
-            depth_list.append(d.reshape(-1))
+            if raw_depth is not None:                 # uploaded as uint16, scaled + resized on the device
+                d = np.asarray(raw_depth[fid])
+                if d.dtype != np.uint16 or d.ndim != 2:
+                    raise ValueError(f"raw depth {fid}: expected a 2-D uint16 array")
+                depth_list.append(d)
+            else:
+                d = np.asarray(scene.depths[fid], dtype=np.float32)
+                if d.shape != (h, w):
+                    raise ValueError(f"depth {fid}: shape {d.shape} != ({h},{w})")
+                depth_list.append(d.reshape(-1))
+            depth_slot[fid] = len(depth_list) - 1
         return depth_slot[fid]
 
     inv, d_idx, f_mask, f_rowbase, f_nmask, f_flags = [], [], [], [], [], []
@@ -205,10 +212,24 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True)
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(dev)
 
     nf = len(inv)
+    if raw_depth is not None and depth_list:
+        from . import _lib
+        from .io import bilinear_taps
+        raw = np.stack(depth_list)
+        hs, ws = raw.shape[1:]
+        taps = None
+        if (hs, ws) != (h, w):
+            taps = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in bilinear_taps(hs, ws, h, w))
+        host = torch.from_numpy(raw.view(np.int16))
+        if dev.type == "cuda":
+            host = host.pin_memory()
+        depth_dev = _lib.depth_from_u16(host.to(dev, non_blocking=True), h, w, taps)
+    else:
+        depth_dev = t(np.stack(depth_list) if depth_list else np.zeros((0, h * w), np.float32), torch.float32)
     return DeviceScene(
         scene_id=scene.scene_id, n_points=n, nw=nw, height=h, width=w, cam_intr=cam_intr,
         xyz=t(soa, torch.float64),
-        depth=t(np.stack(depth_list) if depth_list else np.zeros((0, h * w), np.float32), torch.float32),
+        depth=depth_dev,
         inv_pose=t(np.stack(inv).reshape(nf, 16) if nf else np.zeros((0, 16)), torch.float64),
         depth_index=t(np.array(d_idx, np.int32), torch.int32), frame_mask=t(np.array(f_mask, np.int32), torch.int32),
         frame_rowbase=t(np.array(f_rowbase, np.int32), torch.int32),

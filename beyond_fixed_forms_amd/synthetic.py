@@ -45,6 +45,8 @@ class SceneInputs:
     height: int = 0
     width: int = 0
     point_object: Optional[np.ndarray] = None   # generator ground truth (not an input)
+    depths_raw: Optional[Dict[str, np.ndarray]] = None   # frame id -> uint16 (h,w) millimetres as stored in the PNG;
+                                                          # when given, /1000 + resize run on the device
 
 
 def _hash32(x: torch.Tensor) -> torch.Tensor:

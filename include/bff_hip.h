@@ -262,6 +262,19 @@ int bff_ratio_keep(const int32_t *masked, const int32_t *viewed, int64_t n_point
                    const float *thr_dev, int32_t use_thr, int64_t nw, uint64_t *keep, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a4 / SURVEY section 8f row 2 -- depth ingestion on the device.  src: uint16 [n_frames][h_src][w_src] raw
+ * depth in millimetres (the decoded 16-bit PNGs, P:432-433); dst: float32 [n_frames][height][width] =
+ * resize(src.astype(f32) / depth_scale, (width, height)) with the bilinear rule of cv2.resize (INTER_LINEAR:
+ * half-pixel centres, edge clamp, horizontal then vertical 2-tap passes in float32, P:436).  The host passes
+ * the tap tables it computed in float64 (x0/x1/ax [width], y0/y1/ay [height]; io.bilinear_taps); with equal
+ * source and target size the tables may be NULL and the call is the plain division.  Uploading 2 B/pixel at
+ * sensor resolution instead of 4 B/pixel at colour resolution cuts the per-scene H2D volume ~8x. */
+int bff_depth_from_u16(const uint16_t *src, int32_t n_frames, int32_t h_src, int32_t w_src,
+                       const int32_t *x0, const int32_t *x1, const float *ax,
+                       const int32_t *y0, const int32_t *y1, const float *ay,
+                       int32_t height, int32_t width, float depth_scale, float *dst, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * a21/a24 -- cosine similarity GEMM on the matrix cores (MFMA f16 -> f32).
  *   cos[i][j] = <a_i, b_j> / (||a_i|| * ||b_j||), float32 accumulate and normalisation
  * (compute_clip_similarity R:93-115; bbox_filter SEG:388-393).  a: f16 [na][dim], b: f16 [nb][dim],

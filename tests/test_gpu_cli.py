@@ -76,7 +76,7 @@ def test_stage_scripts_end_to_end(tmp_path):
     assert ck == {sc.scene_id: True for sc in scenes}
     assert (tmp_path / "checkpoints" / f"refinement_checkpoint_{cls}.yaml").exists()
     # same run storing RLE instead of dense masks: identical content
-    env_rle = dict(env, BFF_SAVE_RLE="1")
+    env_rle = dict(env, BFF_SAVE_RLE="1", BFF_DEPTH_ON_DEVICE="1")      # and depth decoded PNG -> GPU directly
     for script in ("projection_2d_to_3d.py", "refinement.py"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), "--config", str(tmp_path / "config.yaml"),
                             "--cls", cls], cwd=tmp_path, env=env_rle, capture_output=True, text=True, timeout=600)

@@ -436,6 +436,20 @@ def test_point_filters(lib, mode, n):
             assert np.isnan(t2.cpu().numpy()[0])
 
 
+@pytest.mark.parametrize("hs,ws,h,w", [(480, 640, 968, 1296), (48, 64, 97, 131), (120, 160, 120, 160), (100, 90, 37, 41)])
+def test_depth_ingestion_matches_host_restatement(lib, hs, ws, h, w):
+    """uint16 millimetres -> float32 metres at (h, w) on the device == io.resize_bilinear_f32(png / 1000), bit for
+    bit (up- and down-scaling, identity).  Parity against cv2 itself is unpinned (no cv2 offline)."""
+    from beyond_fixed_forms_amd import io
+    rng = np.random.default_rng(hs * w)
+    raw = rng.integers(0, 6000, (3, hs, ws)).astype(np.uint16)
+    raw[0, :5] = 0
+    exp = np.stack([io.resize_bilinear_f32(r.astype(np.float32) / np.float32(1000), w, h) for r in raw])
+    taps = None if (hs, ws) == (h, w) else tuple(torch.from_numpy(a).to(DEV) for a in io.bilinear_taps(hs, ws, h, w))
+    got = lib.depth_from_u16(torch.from_numpy(raw.view(np.int16)).to(DEV), h, w, taps).cpu().numpy().reshape(3, h, w)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
 @pytest.mark.parametrize("na,nb,dim", [(1, 198, 768), (37, 200, 64), (300, 198, 512), (16, 16, 32)])
 def test_cosine_gemm(lib, na, nb, dim):
     """Config 5: CLIP-sized embeddings against a 200-label bank; |cos - f64 reference| <= 1e-4."""

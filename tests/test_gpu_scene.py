@@ -187,6 +187,30 @@ def test_refinement_merge_branches(api, variant):
     same(got["s_00"].to_dict(), exp["s_00"])
 
 
+def test_raw_depth_path_equals_float_depth_path(api):
+    """A scene given as raw uint16 depth at sensor resolution (scaled + resized on the device) gives the same
+    result as the same scene with the depth resized on the host (io.resize_bilinear_f32)."""
+    projection, _ = api
+    from beyond_fixed_forms_amd import io
+    from beyond_fixed_forms_amd.synthetic import make_scene
+    scene = make_scene("tiny", seed=31)
+    small = {f: np.round(d[::2, ::2].astype(np.float64) * 1000).astype(np.uint16) for f, d in scene.depths.items()}
+    host = make_scene("tiny", seed=31)
+    host.depths = {f: io.resize_bilinear_f32(r.astype(np.float32) / np.float32(1000), scene.width, scene.height)
+                   for f, r in small.items()}
+    dev = make_scene("tiny", seed=31)
+    dev.depths, dev.depths_raw = {}, small
+    cfg = cfg_for(scene)
+    a = projection.project_scene(host, cfg, DEV, return_result=True, debug_out=True)
+    b = projection.project_scene(dev, cfg, DEV, return_result=True, debug_out=True)
+    assert torch.equal(a.debug["raw_rows"], b.debug["raw_rows"]) and torch.equal(a.rows, b.rows)
+    assert torch.equal(a.debug["viewed_counts"], b.debug["viewed_counts"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = pref.project_scene_ref(host, cfg)
+    same(b.to_dict(), exp)
+
+
 def test_empty_inputs(api):
     """No 2-D masks at all (P:465-478) and nothing merged (P:496-509): the reference's empty form."""
     projection, refinement = api
