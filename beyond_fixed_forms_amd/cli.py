@@ -46,6 +46,14 @@ def projection_main(argv=None):
     return 0
 
 
+def _clip_available():
+    try:
+        import clip  # noqa: F401
+        return True
+    except ImportError:
+        return False
+
+
 def _text_encoder(path):
     """CLIP ViT-L/14 text encoder (R:147) when the `clip` package is importable; otherwise a file of
     precomputed text embeddings {text: (D,) tensor} given by BFF_TEXT_EMBEDDINGS."""
@@ -69,7 +77,14 @@ def refinement_main(argv=None):
     _lib.load()
     cls = args.cls
     ckpt = read_scene_checkpoint("refinement", cls)
-    sim = TextSimilarity(_text_encoder(os.environ.get("BFF_TEXT_EMBEDDINGS")), "cuda")
+    # BFF_TEXT_BANK=<file>: similarity service persisted by an earlier run (bank of the 198 labels + queries);
+    # created on first use, so the CLIP text encoder runs once per label ever, not twice per matched mask
+    bank_file = os.environ.get("BFF_TEXT_BANK")
+    if bank_file and os.path.exists(bank_file):
+        need_enc = os.environ.get("BFF_TEXT_EMBEDDINGS") or _clip_available()
+        sim = TextSimilarity.from_file(bank_file, "cuda", _text_encoder(os.environ.get("BFF_TEXT_EMBEDDINGS")) if need_enc else None)
+    else:
+        sim = TextSimilarity(_text_encoder(os.environ.get("BFF_TEXT_EMBEDDINGS")), "cuda")
     stage2_dir = os.path.join(cfg.mask_3d_dir, cls)
     scenes = []
     for name in sorted(s for s in os.listdir(stage2_dir) if s.endswith("_00.pth")):        # R:154
@@ -83,6 +98,8 @@ def refinement_main(argv=None):
         else:
             scenes.append((scene_id, None, None))
     out = refine_class(scenes, cfg, cls, sim, "cuda")
+    if bank_file:
+        sim.save(bank_file)
     for scene_id, res in out.items():
         d = res.to_rle_dict() if os.environ.get("BFF_SAVE_RLE") == "1" else res.to_dict()
         d = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in d.items()}               # reference saves CPU tensors

@@ -37,6 +37,34 @@ class TextSimilarity:
         self.encode_text = encode_text
         self.index = {lab: i for i, lab in enumerate(self.labels)}
         self._cache: Dict[str, np.ndarray] = {}
+        self._query_emb: Dict[str, torch.Tensor] = {}
+
+    def save(self, path: str):
+        """Persist the label bank and every query embedding seen so far (plain tensors + strings), so later
+        class runs need no text encoder at all."""
+        torch.save({"labels": self.labels, "bank": self.bank.cpu(), "queries": dict(self._query_emb)}, path)
+
+    @classmethod
+    def from_file(cls, path: str, device="cuda", encode_text: Optional[Callable[[str], torch.Tensor]] = None):
+        """Rebuild the service from `save()` output (loaded with weights_only=True: tensors and strings only).
+        Queries missing from the file need `encode_text`."""
+        blob = torch.load(path, map_location="cpu", weights_only=True)
+        self = cls.__new__(cls)
+        self.device = torch.device(device)
+        self.labels = list(blob["labels"])
+        self.bank = blob["bank"].to(torch.float16).to(self.device).contiguous()
+        self.index = {lab: i for i, lab in enumerate(self.labels)}
+        self._cache = {}
+        self._query_emb = dict(blob.get("queries", {}))
+
+        def enc(text):
+            if text in self._query_emb:
+                return self._query_emb[text]
+            if encode_text is None:
+                raise KeyError(f"no embedding for {text!r} in {path} and no text encoder given")
+            return encode_text(text)
+        self.encode_text = enc
+        return self
 
     @staticmethod
     def _pad(x):
@@ -48,7 +76,9 @@ class TextSimilarity:
         """float32 [n_labels]: cosine of `text` against every bank label."""
         if text not in self._cache:
             with torch.no_grad():
-                q = self._pad(self.encode_text(text).reshape(1, -1).to(torch.float16)).to(self.device).contiguous()
+                emb = self.encode_text(text).reshape(1, -1).to(torch.float16)
+                self._query_emb[text] = emb.cpu()
+                q = self._pad(emb).to(self.device).contiguous()
             self._cache[text] = _lib.cosine_gemm_f16(q, self.bank)[0].cpu().numpy()
         return self._cache[text]
 

@@ -211,6 +211,22 @@ def test_raw_depth_path_equals_float_depth_path(api):
     same(b.to_dict(), exp)
 
 
+def test_text_bank_round_trip(api, tmp_path):
+    """The similarity service saved to disk and reloaded without any text encoder gives identical similarities."""
+    _, refinement = api
+    from beyond_fixed_forms_amd.synthetic import make_text_bank
+    bank, index = make_text_bank(96, seed=3)                 # 96 -> padded to a multiple of 32 internally
+    sim = refinement.TextSimilarity(bank_encoder(bank.float(), index), DEV)
+    a = sim.similarities("table", ["chair", "office_chair", "table"])
+    sim.save(str(tmp_path / "bank.pt"))
+    sim2 = refinement.TextSimilarity.from_file(str(tmp_path / "bank.pt"), DEV)
+    assert sim2.similarities("table", ["chair", "office_chair", "table"]) == a
+    with pytest.raises(KeyError):
+        sim2.similarities("never seen query", ["chair"])
+    exp = torch.nn.functional.cosine_similarity(bank[index["table"]].double()[None], bank[[index[k] for k in ("chair", "office_chair", "table")]].double())
+    assert np.abs(np.array(a) - exp.numpy()).max() <= 1e-4
+
+
 def test_empty_inputs(api):
     """No 2-D masks at all (P:465-478) and nothing merged (P:496-509): the reference's empty form."""
     projection, refinement = api
