@@ -83,3 +83,54 @@ def gather_final_rows(rows: torch.Tensor, dst: int = 0):
     if rank != dst:
         return None
     return [b[:int(s[0]), :int(s[1])].to(dev) for b, s in zip(bufs, shapes)]
+
+
+def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[float] = None):
+    """One query class over many scenes on all ranks (the multi-GPU form of running
+    tools/projection_2d_to_3d.py + tools/refinement.py for that class).
+
+    scenes: list of SceneInputs-like objects (same list on every rank; only the rank's shard is touched).
+    Rank r projects and refines the scenes `shard_scenes` gives it; the similarity sets are pooled across
+    ranks before the threshold is taken (refinement.py:316-324), so every rank applies the threshold the
+    single-process class loop would.  Returns, on rank 0, {scene_id: (rows int64 [R][nw] or None, conf,
+    final_class)} for ALL scenes (bit rows gathered over RCCL, small metadata over the object channel);
+    on the other ranks the dict of their own shard."""
+    from .projection import run_projection
+    from .refinement import prepare_stage1, refine_class
+    from .scene import prepare_scene
+    rank, ws = world()
+    mine = shard_scenes([s.scene_id for s in scenes], weights=weights)
+    trip = []
+    for i in mine:
+        ds = prepare_scene(scenes[i], cfg, device=device)
+        trip.append((scenes[i].scene_id, prepare_stage1(scenes[i].stage1, device), run_projection(ds, cfg)))
+    exchange = (lambda sims: exchange_similarities(sims, device=device)) if ws > 1 else None
+    final = refine_class(trip, cfg, text_prompt, sim, device, exchange_sims=exchange) if trip or ws > 1 else {}
+    local = {sid: (r.rows, r.conf, list(r.final_class)) for sid, r in final.items()}
+    if ws == 1:
+        return local
+    # rows of all local scenes stacked into one [sum R][nw_max] buffer -> one gather; metadata as objects
+    nw_max = max([r.shape[1] for r, _, _ in local.values() if r is not None] + [1])
+    parts, meta = [], []
+    for sid, (rows, conf, cls) in local.items():
+        k = 0 if rows is None else rows.shape[0]
+        if k:
+            pad = torch.zeros((k, nw_max), dtype=torch.int64, device=device)
+            pad[:, :rows.shape[1]] = rows
+            parts.append(pad)
+        meta.append((sid, k, None if rows is None else rows.shape[1],
+                     conf if isinstance(conf, list) else conf.cpu(), cls, rows is None))
+    stacked = torch.cat(parts) if parts else torch.zeros((0, nw_max), dtype=torch.int64, device=device)
+    gathered = gather_final_rows(stacked)
+    metas = [None] * ws
+    dist.all_gather_object(metas, meta)
+    if rank != 0:
+        return local
+    out = {}
+    for r in range(ws):
+        at = 0
+        for sid, k, nw, conf, cls, is_list in metas[r]:
+            rows = None if is_list else gathered[r][at:at + k, :nw].contiguous()
+            at += k
+            out[sid] = (rows, conf, cls)
+    return out

@@ -258,3 +258,63 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libbff_hip.so")
     with pytest.raises(_lib.BffLibraryError):
         _lib.load()
+
+
+def _run_class_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share the box's one GPU
+    from beyond_fixed_forms_amd import distributed as bd
+    from beyond_fixed_forms_amd.config import Config
+    from beyond_fixed_forms_amd.refinement import TextSimilarity
+    from beyond_fixed_forms_amd.synthetic import make_scene, make_text_bank
+    scenes = [make_scene("tiny", seed=50 + i) for i in range(5)]
+    for i, sc in enumerate(scenes):
+        sc.scene_id = f"scene{50 + i:04d}_00"
+    cfg = Config.with_defaults(width_2d=scenes[0].width, height_2d=scenes[0].height)
+    bank, index = make_text_bank(64, seed=7)
+    out = bd.run_class(scenes, cfg, "table", TextSimilarity(bank_encoder(bank.float(), index), DEV), DEV,
+                       weights=[s.points.shape[0] * len(s.mask_2d) for s in scenes])
+    if rank == 0:
+        q.put({sid: (None if r is None else r.cpu(), c if isinstance(c, list) else c.cpu(), cls) for sid, (r, c, cls) in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_class_two_ranks_equals_single_process(api):
+    """distributed.run_class with 2 ranks (sharded scenes, pooled similarity sets, gathered bit rows) gives,
+    on rank 0, exactly the results of the single-process class loop -- and of the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    projection, refinement = api
+    from beyond_fixed_forms_amd.synthetic import make_scene, make_text_bank
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_run_class_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = q.get(timeout=300)
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    scenes = [make_scene("tiny", seed=50 + i) for i in range(5)]
+    for i, sc in enumerate(scenes):
+        sc.scene_id = f"scene{50 + i:04d}_00"
+    cfg = cfg_for(scenes[0])
+    bank, index = make_text_bank(64, seed=7)
+    enc = bank_encoder(bank.float(), index)
+    trip = []
+    for sc in scenes:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            trip.append((sc.scene_id, sc.stage1, pref.project_scene_ref(sc, cfg)))
+    exp = rref.refine_class_ref(trip, cfg, "table", enc)
+    assert sorted(got) == sorted(exp)
+    for sid, (rows, conf, cls) in got.items():
+        e = exp[sid]
+        if isinstance(e["ins"], list):
+            assert rows is None and cls == []
+            continue
+        n = e["ins"].shape[1]
+        dense = np.unpackbits(rows.numpy().view(np.uint8), axis=-1, bitorder="little")[:, :n].astype(bool)
+        assert np.array_equal(dense, e["ins"].numpy()) and torch.equal(conf, e["conf"]) and cls == e["final_class"]
