@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 from beyond_fixed_forms_amd import _lib, distributed as bdist  # noqa: E402
 from beyond_fixed_forms_amd.config import Config  # noqa: E402
-from beyond_fixed_forms_amd.projection import run_projection  # noqa: E402
+from beyond_fixed_forms_amd.projection import projection_back, projection_front  # noqa: E402
 from beyond_fixed_forms_amd.refinement import TextSimilarity, prepare_stage1, refine_class  # noqa: E402
 from beyond_fixed_forms_amd.scene import prepare_scene  # noqa: E402
 from beyond_fixed_forms_amd.synthetic import SHAPES, make_scene, make_text_bank  # noqa: E402
@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape", default="c2", choices=list(SHAPES) + ["c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="finish every scene before starting the next (default: the GPU-only front half of the next "
+                         "scene is issued on a second HIP stream while the host finishes the current one)")
     args = ap.parse_args()
     if args.shape == "c5":
         return bench_cosine(args)
@@ -179,18 +182,40 @@ def main():
         dist.barrier()
 
     timers = KernelTimers()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
 
-    def step(tm=None):
-        res = run_projection(ds, cfg, timers=tm)
-        fin = refine_class([(scene.scene_id, stage1, res)], cfg, QUERY, sim, dev, exchange_sims=exchange)
-        rows = fin[scene.scene_id].rows
-        if rows is None:
-            rows = torch.zeros((0, ds.nw), dtype=torch.int64, device=dev)
-        gathered = bdist.gather_final_rows(rows)
+    def front(i, tm=None):
+        with torch.cuda.stream(streams[i % 2]):
+            return projection_front(ds, cfg, timers=tm)
+
+    def back(i, fr):
+        with torch.cuda.stream(streams[i % 2]):
+            res = projection_back(fr)
+            fin = refine_class([(scene.scene_id, stage1, res)], cfg, QUERY, sim, dev, exchange_sims=exchange)
+            rows = fin[scene.scene_id].rows
+            if rows is None:
+                rows = torch.zeros((0, ds.nw), dtype=torch.int64, device=dev)
+            gathered = bdist.gather_final_rows(rows)
         return res, fin, gathered
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(k, tm=None):
+        """k scenes, one after the other through the whole path.  Pipelined form: while the host works on the
+        back half of scene i (read-backs, grouping, refinement), the front half of scene i+1 (decode, sweep,
+        components: no host dependency) already runs on the other stream."""
+        out = None
+        if args.no_pipeline:
+            for i in range(k):
+                out = back(i, front(i, tm))
+            return out
+        nxt = front(0, tm) if k else None
+        for i in range(k):
+            cur = nxt
+            if i + 1 < k:
+                nxt = front(i + 1, tm)
+            out = back(i, cur)
+        return out
+
+    run_steps(args.warmup)
 
     def fence():
         torch.cuda.synchronize()
@@ -200,8 +225,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res, fin, gathered = step(timers)
+    res, fin, gathered = run_steps(args.steps, timers)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -228,7 +252,9 @@ def main():
             "config": {"workload": f"{args.shape}: 1 scene/GPU, {n} pts x {len(scene.mask_2d)} mask views + "
                                    f"{ds.n_viewed} viewed frames @{h}x{w}, {m} masks/view (Ins={ds.n_rows}), "
                                    f"stage-1 S1={len(scene.stage1['ins'])}, 198x768 f16 text bank",
-                       "scenes_per_step": world, "sharding": "one scene per GPU, RCCL gather of final masks"},
+                       "scenes_per_step": world, "sharding": "one scene per GPU, RCCL gather of final masks",
+                       "pipelining": "none" if args.no_pipeline else
+                       "2 HIP streams: front half of scene i+1 overlaps the host-side back half of scene i"},
             "roofline": {"bound": "hbm", "kernel": "project_views_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": pv[2], "launches": pv[0]},

@@ -95,15 +95,38 @@ def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[floa
     single-process class loop would.  Returns, on rank 0, {scene_id: (rows int64 [R][nw] or None, conf,
     final_class)} for ALL scenes (bit rows gathered over RCCL, small metadata over the object channel);
     on the other ranks the dict of their own shard."""
-    from .projection import run_projection
+    from .projection import projection_back, projection_front
     from .refinement import prepare_stage1, refine_class
     from .scene import prepare_scene
     rank, ws = world()
     mine = shard_scenes([s.scene_id for s in scenes], weights=weights)
+    # two-stage software pipeline over two HIP streams: the GPU-only front half of scene k+1 (decode, sweep,
+    # components) is issued before the host finishes the back half of scene k
+    streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)] if torch.device(device).type == "cuda" else None
+
+    def front(k):
+        ds = prepare_scene(scenes[mine[k]], cfg, device=device)
+        if streams is None:
+            return projection_front(ds, cfg)
+        streams[k % 2].wait_stream(torch.cuda.current_stream())       # the upload ran on the current stream
+        with torch.cuda.stream(streams[k % 2]):
+            return projection_front(ds, cfg)
+
+    def back(k, fr):
+        if streams is None:
+            return projection_back(fr)
+        with torch.cuda.stream(streams[k % 2]):
+            res = projection_back(fr)
+        torch.cuda.current_stream().wait_stream(streams[k % 2])       # results are used on the current stream
+        return res
+
     trip = []
-    for i in mine:
-        ds = prepare_scene(scenes[i], cfg, device=device)
-        trip.append((scenes[i].scene_id, prepare_stage1(scenes[i].stage1, device), run_projection(ds, cfg)))
+    nxt = front(0) if mine else None
+    for k, i in enumerate(mine):
+        cur = nxt
+        if k + 1 < len(mine):
+            nxt = front(k + 1)
+        trip.append((scenes[i].scene_id, prepare_stage1(scenes[i].stage1, device), back(k, cur)))
     exchange = (lambda sims: exchange_similarities(sims, device=device)) if ws > 1 else None
     final = refine_class(trip, cfg, text_prompt, sim, device, exchange_sims=exchange) if trip or ws > 1 else {}
     local = {sid: (r.rows, r.conf, list(r.final_class)) for sid, r in final.items()}

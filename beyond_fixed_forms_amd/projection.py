@@ -9,7 +9,7 @@ sets of distinct values, and dict assembly.  `P:` = tools/projection_2d_to_3d.py
 from __future__ import annotations
 
 import dataclasses
-from typing import List
+from typing import List, Optional
 
 import numpy as np
 import torch
@@ -147,28 +147,39 @@ def component_csr(comp: np.ndarray, has_self_loop: np.ndarray, min_members: int)
     return offs, members, sizes, int(void.sum()) if min_members <= 0 else 0
 
 
-def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, phases=None) -> Stage2Result:
-    """P:402-634 for one uploaded scene.  `phases` (dict, diagnostic): wall time per phase with a device
-    synchronize at every phase boundary."""
+@dataclasses.dataclass
+class _Front:
+    """Everything the GPU-only first half of a scene leaves behind (all device tensors live on the stream the
+    front was issued on)."""
+    ds: DeviceScene
+    cfg: object
+    dbg: dict
+    debug_out: bool
+    rows: Optional[torch.Tensor] = None
+    masked: Optional[torch.Tensor] = None
+    viewed: Optional[torch.Tensor] = None
+    keep: Optional[torch.Tensor] = None
+    thr_dev: Optional[torch.Tensor] = None
+    lat_info: Optional[torch.Tensor] = None
+    area: Optional[torch.Tensor] = None
+    comp: Optional[torch.Tensor] = None
+    do_ratio: bool = False
+
+
+def projection_front(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -> _Front:
+    """First half of P:402-634 for one uploaded scene: RLE decode, fused sweep, point-filter threshold, row
+    statistics and the components of the merge graph.  Pure device work -- nothing here waits for the GPU, so
+    a caller can issue the front of the next scene on another stream while the host finishes this one
+    (`projection_back`)."""
     with _lib.launch_stream():
-        return _run_projection(ds, cfg, debug_out, timers, phases)
+        return _projection_front(ds, cfg, debug_out, timers)
 
 
-def _run_projection(ds: DeviceScene, cfg, debug_out, timers, phases) -> Stage2Result:
-    import time
-    _t = [time.perf_counter()]
-
-    def mark(name):
-        if phases is not None:
-            torch.cuda.synchronize()
-            now = time.perf_counter()
-            phases[name] = phases.get(name, 0.0) + (now - _t[0])
-            _t[0] = now
-
+def _projection_front(ds, cfg, debug_out, timers) -> _Front:
     dev = ds.xyz.device
-    dbg = {}
+    fr = _Front(ds, cfg, {}, debug_out)
     n, nw = ds.n_points, ds.nw
-    do_ratio = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
+    do_ratio = fr.do_ratio = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
 
     # a1: RLE -> per-pixel mask words (never the dense (M,1,H,W) tensors of P:400)
     n_mviews = ds.view_mask_offs.shape[0] - 1
@@ -180,9 +191,9 @@ def _run_projection(ds: DeviceScene, cfg, debug_out, timers, phases) -> Stage2Re
                              ds.height * ds.width, ds.word_bits, maskbits, segmap)
 
     # a2-a8 (+a15): one fused sweep over the frames (P:413-461 and P:538-567)
-    rows = torch.empty((ds.n_rows, nw), dtype=torch.int64, device=dev)
-    masked = torch.zeros(n, dtype=torch.int32, device=dev)                          # P:402
-    viewed = torch.zeros(n, dtype=torch.int32, device=dev) if do_ratio else None    # P:537
+    rows = fr.rows = torch.empty((ds.n_rows, nw), dtype=torch.int64, device=dev)
+    masked = fr.masked = torch.zeros(n, dtype=torch.int32, device=dev)                          # P:402
+    viewed = fr.viewed = torch.zeros(n, dtype=torch.int32, device=dev) if do_ratio else None    # P:537
     n_frames = ds.n_frames if do_ratio else ds.n_mask_frames
     with span(timers, "project_views"):
         _lib.project_views(ds.xyz, n, ds.inv_pose[:n_frames], ds.cam_intr, ds.depth, ds.depth_index, ds.height,
@@ -193,40 +204,80 @@ def _run_projection(ds: DeviceScene, cfg, debug_out, timers, phases) -> Stage2Re
     # a14/a15: point filter (P:512-583), entirely on the device: the threshold never visits the host
     if cfg.if_occurance_threshold or do_ratio:
         frac = cfg.detected_ratio_threshold if do_ratio else cfg.occurance_threshold
-        thr_dev, lat_info = _lib.point_threshold(masked, viewed if do_ratio else None, frac)
-        keep = _lib.ratio_keep(masked, viewed if do_ratio else None, thr_dev, True)
+        fr.thr_dev, fr.lat_info = _lib.point_threshold(masked, viewed if do_ratio else None, frac)
+        fr.keep = _lib.ratio_keep(masked, viewed if do_ratio else None, fr.thr_dev, True)
     else:
-        thr_dev = lat_info = None
-        keep = _lib.ratio_keep(masked, None, 0.0, False)
-    mark("decode+sweep")
-    # per-point arrays and bit rows are in the (spatially sorted) device point order; `unsorted` maps
-    # bit rows back to the caller's point order
-    unsorted = (lambda r: _lib.permute_bits(r, ds.unsort, n)) if ds.unsort is not None else (lambda r: r)
-    if debug_out:
-        back = (lambda v: v[ds.unsort.long()]) if ds.unsort is not None else (lambda v: v.clone())
-        dbg["raw_rows"], dbg["masked_counts_raw"] = unsorted(rows), back(masked)
+        fr.keep = _lib.ratio_keep(masked, None, 0.0, False)
     if ds.n_rows == 0:                                                              # P:465-478
-        return _empty(ds, dbg)
+        return fr
 
     # a9-a12: components of the IoU / label merge graph (P:100-146, 250-274) in one pass.  Rows are tiled
     # in the order (label, heavy-bin signature) so that a tile's rows occupy few chunks.
     with span(timers, "row_stats"):
         area, _mean_word, cmask, hist, sig = _lib.row_stats(rows)
         order = torch.argsort(sig, stable=True)
-        if len(set(ds.labels)) > 1:               # several label strings: cluster by label first
+        if ds.n_label_ids > 1:                    # several label strings: cluster by label first
             order = order[torch.argsort(ds.label_id[order], stable=True)]
         order = order.to(torch.int32)
     with span(timers, "merge_components"):
-        comp = _lib.merge_components(rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist)
-        got = _lib.fetch(comp, area, *([lat_info, thr_dev] if lat_info is not None else []))   # one sync
-        comp_h, area_h = got[0], got[1]
-    if lat_info is not None:
+        fr.comp = _lib.merge_components(rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist)
+    fr.area = area
+    return fr
+
+
+def projection_back(fr: _Front, timers=None, phases=None) -> Stage2Result:
+    """Second half: read the components back, group, merge, filter, select (P:203-247, 583-634).  Must run on
+    the stream the front was issued on."""
+    with _lib.launch_stream():
+        return _projection_back(fr, timers, phases)
+
+
+def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, phases=None) -> Stage2Result:
+    """P:402-634 for one uploaded scene.  `phases` (dict, diagnostic): wall time per phase with a device
+    synchronize at every phase boundary."""
+    if phases is not None:
+        import time
+        t0 = time.perf_counter()
+    fr = projection_front(ds, cfg, debug_out, timers)
+    if phases is not None:
+        torch.cuda.synchronize()
+        phases["front (decode, sweep, threshold, stats, components)"] = \
+            phases.get("front (decode, sweep, threshold, stats, components)", 0.0) + time.perf_counter() - t0
+    return projection_back(fr, timers, phases)
+
+
+def _projection_back(fr: _Front, timers, phases) -> Stage2Result:
+    import time
+    _t = [time.perf_counter()]
+
+    def mark(name):
+        if phases is not None:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            phases[name] = phases.get(name, 0.0) + (now - _t[0])
+            _t[0] = now
+
+    ds, cfg, dbg, debug_out = fr.ds, fr.cfg, fr.dbg, fr.debug_out
+    dev = ds.xyz.device
+    n = ds.n_points
+    rows, masked, viewed, keep, do_ratio = fr.rows, fr.masked, fr.viewed, fr.keep, fr.do_ratio
+    # per-point arrays and bit rows are in the (spatially sorted) device point order; `unsorted` maps
+    # bit rows back to the caller's point order
+    unsorted = (lambda r: _lib.permute_bits(r, ds.unsort, n)) if ds.unsort is not None else (lambda r: r)
+    back = (lambda v: v[ds.unsort.long()]) if ds.unsort is not None else (lambda v: v.clone())
+    if debug_out:
+        dbg["raw_rows"], dbg["masked_counts_raw"] = unsorted(rows), back(masked)
+    if ds.n_rows == 0:                                                              # P:465-478
+        return _empty(ds, dbg)
+    got = _lib.fetch(fr.comp, fr.area, *([fr.lat_info, fr.thr_dev] if fr.lat_info is not None else []))   # one sync
+    comp_h, area_h = got[0], got[1]
+    if fr.lat_info is not None:
         if got[2][0] == 0 or np.isnan(got[3][0]):
             raise IndexError("index out of range: unique()[floor(t * n)] (P:516 / P:574)")
         dbg["thr"] = float(got[3][0])
         if debug_out and do_ratio:
             dbg["viewed_counts"] = back(viewed)
-    mark("stats+components")
+    mark("read-back")
     self_loop = (area_h > 0) & bool(np.float32(1.0) > np.float32(cfg.iou_thres))
     csr = _lib.host_component_csr(comp_h, self_loop, cfg.min_aggragated_masks)                    # P:203
     offs, members, sizes, n_void = csr if csr is not None else component_csr(comp_h, self_loop, cfg.min_aggragated_masks)
@@ -248,6 +299,7 @@ def _run_projection(ds: DeviceScene, cfg, debug_out, timers, phases) -> Stage2Re
     agg_labels = [ds.labels[i] for i in first_member]
     if not debug_out:
         del rows
+        fr.rows = None
     mark("grouping+or_reduce")
 
     # a16: overlap resolution (P:592-596), decided and applied on the device

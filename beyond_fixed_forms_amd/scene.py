@@ -109,6 +109,7 @@ class DeviceScene:
     conf: torch.Tensor                   # (Ins,) float16/float32 device
     labels: List[str]                    # Ins label strings (host)
     label_id: torch.Tensor               # i32 [Ins]
+    n_label_ids: int = 1                 # number of distinct label strings
     stage1: Optional[dict] = None
     unsort: Optional[torch.Tensor] = None   # i32 [N]: position of original point o in the sorted cloud (None = unsorted)
 
@@ -237,5 +238,5 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True)
         n_frames=nf, n_mask_frames=n_mask_frames, n_viewed=len(viewed), word_bits=word_bits, n_rows=row,
         run_start=t(rs, torch.int32), run_end=t(re, torch.int32), mask_run_offs=t(roffs, torch.int32),
         view_mask_offs=t(np.array(view_mask_offs, np.int32), torch.int32),
-        conf=conf.to(dev), labels=labels, label_id=t(label_id, torch.int32),
+        conf=conf.to(dev), labels=labels, label_id=t(label_id, torch.int32), n_label_ids=max(1, len(ids)),
         stage1=getattr(scene, "stage1", None), unsort=None if unsort is None else t(unsort, torch.int32))
