@@ -131,12 +131,17 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// 2-D RLE -> mask words.  One block walks a band of `kChunksPerBand` chunks of one mask-view; thread
-// b < n_masks keeps a cursor into mask b's (sorted, disjoint) run list.  Per chunk the runs are
-// entered as XOR toggles at their clipped start and end in LDS, an XOR prefix scan turns toggles
-// into coverage, and the chunk is written once, coalesced.  HBM traffic = one write of the image.
-constexpr int kChunk = 2048;                 // pixels per chunk (8 per thread)
-constexpr int kChunksPerBand = 16;
+// 2-D RLE -> mask words, wave-synchronous.  Every wave owns a band of kWaveChunks x 512 pixels of one
+// mask-view and a private 512-word LDS slice; lane b < n_masks keeps mask b's run cursor (current + next
+// run in registers).  Per 512-pixel chunk the runs enter LDS as XOR toggles at their clipped start and end,
+// an XOR prefix scan (4 + 4 words per lane, wave shuffles) turns toggles into coverage, and the chunk is
+// written with two fully coalesced 1-KiB (u32) stores.  There is no block barrier: waves never wait for each
+// other, LDS accesses of one wave complete in issue order.  Segments of 128 pixels without any mask pixel
+// are not written when a segment bitmap is requested.  HBM traffic = at most one write of the image.
+constexpr int kWaveChunk = 512;              // pixels per wave chunk (4 + 4 per lane)
+constexpr int kWaveChunks = 32;              // chunks per wave band (16384 pixels)
+
+__device__ __forceinline__ void lds_phase_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <typename WordT>
 __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
@@ -144,23 +149,22 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
     const int32_t *__restrict__ mask_run_offs, const int32_t *__restrict__ view_mask_offs,
     int64_t n_pixels, WordT *__restrict__ maskbits, uint32_t *__restrict__ segmap, int64_t seg_words)
 {
-    __shared__ WordT bits[kChunk];
-    __shared__ WordT wave_tot[2][2 * kBlock / kWave];  // [parity][half * 4 + wave]; double buffered across chunks
+    __shared__ WordT lds[kBlock / kWave][kWaveChunk];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WordT *bits = lds[wave];
     const int v = blockIdx.y;
     const int g0 = view_mask_offs[v];
     const int nm = view_mask_offs[v + 1] - g0;
-    const int64_t band0 = (int64_t)blockIdx.x * kChunk * kChunksPerBand;
+    const int64_t band0 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kWaveChunk * kWaveChunks;
+    if (band0 >= n_pixels) return;                   // wave-uniform
     WordT *img = maskbits + (int64_t)v * n_pixels;
 
-    // Thread b < nm walks mask b's runs; the current and the next run stay in registers so that a chunk
-    // costs no dependent global loads unless the cursor advances (and then the load is already in flight).
     constexpr int64_t kNone = INT64_MAX;
     int cur = 0, hi = 0;
     int64_t rs = kNone, re = kNone, ns = kNone, ne = kNone;
-    if (tid < nm) {
-        int lo = mask_run_offs[g0 + tid];
-        hi = mask_run_offs[g0 + tid + 1];
+    if (lane < nm) {
+        int lo = mask_run_offs[g0 + lane];
+        hi = mask_run_offs[g0 + lane + 1];
         int r = hi;                                   // first run with end > band0
         while (lo < r) {
             const int mid = (lo + r) >> 1;
@@ -170,18 +174,16 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
         if (cur < hi) { rs = run_start[cur]; re = run_end[cur]; }
         if (cur + 1 < hi) { ns = run_start[cur + 1]; ne = run_end[cur + 1]; }
     }
-    // Word ownership: thread t owns words [4t, 4t+4) of each 1024-word half of the chunk, so that one
-    // store instruction of a wave covers 1 KiB contiguously (16 B per lane).
-    constexpr int kHalf = kChunk / 2, kQ = 4;
+    constexpr int kHalf = kWaveChunk / 2, kQ = 4;     // lane owns words [4l, 4l+4) of each 256-word half
 #pragma unroll
-    for (int k = 0; k < kQ; ++k) { bits[tid * kQ + k] = 0; bits[kHalf + tid * kQ + k] = 0; }
-    __syncthreads();
-    for (int c = 0; c < kChunksPerBand; ++c) {
-        const int64_t c0 = band0 + (int64_t)c * kChunk;
+    for (int k = 0; k < kQ; ++k) { bits[lane * kQ + k] = 0; bits[kHalf + lane * kQ + k] = 0; }
+    lds_phase_fence();
+    for (int c = 0; c < kWaveChunks; ++c) {
+        const int64_t c0 = band0 + (int64_t)c * kWaveChunk;
         if (c0 >= n_pixels) break;
-        const int64_t c1 = min(c0 + kChunk, n_pixels);
-        if (tid < nm) {
-            const WordT bit = (WordT)1 << tid;
+        const int64_t c1 = min(c0 + kWaveChunk, n_pixels);
+        if (lane < nm) {
+            const WordT bit = (WordT)1 << lane;
             while (rs < c1) {
                 atomicXor(&bits[(int)(max(rs, c0) - c0)], bit);
                 if (re < c1) atomicXor(&bits[(int)(re - c0)], bit);
@@ -191,42 +193,40 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
                 if (cur + 1 < hi) { ns = run_start[cur + 1]; ne = run_end[cur + 1]; } else { ns = ne = kNone; }
             }
         }
-        __syncthreads();
-        // XOR prefix scan of the two halves; words are re-zeroed as they are read
+        lds_phase_fence();                            // toggles of all lanes are in LDS
         WordT loc[2][kQ], tot[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             WordT acc = 0;
 #pragma unroll
             for (int k = 0; k < kQ; ++k) {
-                acc ^= bits[h * kHalf + tid * kQ + k];
+                acc ^= bits[h * kHalf + lane * kQ + k];
                 loc[h][k] = acc;
-                bits[h * kHalf + tid * kQ + k] = 0;
+                bits[h * kHalf + lane * kQ + k] = 0;  // ready for the next chunk
             }
             tot[h] = acc;
         }
+        lds_phase_fence();                            // re-zeroing is ordered before the next chunk's toggles
         WordT incl[2] = {tot[0], tot[1]};
 #pragma unroll
         for (int d = 1; d < kWave; d <<= 1) {
             const WordT u0 = __shfl_up(incl[0], d), u1 = __shfl_up(incl[1], d);
             if (lane >= d) { incl[0] ^= u0; incl[1] ^= u1; }
         }
-        if (lane == kWave - 1) { wave_tot[c & 1][wave] = incl[0]; wave_tot[c & 1][4 + wave] = incl[1]; }
-        __syncthreads();                              // also orders the re-zeroing before the next toggles
-        WordT carry0 = incl[0] ^ tot[0], carry1 = incl[1] ^ tot[1];          // exclusive within the wave
-        for (int q = 0; q < wave; ++q) { carry0 ^= wave_tot[c & 1][q]; carry1 ^= wave_tot[c & 1][4 + q]; }
-        for (int q = 0; q < 4; ++q) carry1 ^= wave_tot[c & 1][q];            // second half continues the first
+        const WordT half0_total = __shfl(incl[0], kWave - 1);
+        const WordT carry0 = incl[0] ^ tot[0];                       // exclusive prefix within the half
+        const WordT carry1 = incl[1] ^ tot[1] ^ half0_total;         // second half continues the first
         using Vec = __attribute__((ext_vector_type(4))) uint32_t;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const WordT carry = h ? carry1 : carry0;
-            const int64_t p0 = c0 + h * kHalf + (int64_t)tid * kQ;
+            const int64_t p0 = c0 + h * kHalf + (int64_t)lane * kQ;
             WordT outv[kQ];
             WordT any = 0;
 #pragma unroll
             for (int k = 0; k < kQ; ++k) { outv[k] = loc[h][k] ^ carry; any |= outv[k]; }
             if (segmap) {
-                // 128-pixel segments = 32 consecutive threads: all-zero segments are not stored at all, the
+                // 128-pixel segments = 32 consecutive lanes: all-zero segments are not stored at all, the
                 // sweep learns from the bitmap (one bit per segment) that there is nothing to gather there
                 const uint64_t nz = __ballot(any != 0);
                 const uint32_t half_nz = (uint32_t)(nz >> (lane & 32));
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
             }
             if (p0 + kQ <= c1) {
                 const Vec *src = reinterpret_cast<const Vec *>(outv);
-                Vec *dst = reinterpret_cast<Vec *>(img + p0);      // chunk starts are multiples of 2048 words
+                Vec *dst = reinterpret_cast<Vec *>(img + p0);      // chunk starts are multiples of 512 words
 #pragma unroll
                 for (int k = 0; k < (int)(kQ * sizeof(WordT) / 16); ++k) dst[k] = src[k];
             } else {
@@ -263,7 +263,7 @@ extern "C" int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_
     BFF_LIMIT(n_pixels < (1ll << 31), "bff_rle_to_maskbits: image larger than 2^31 pixels");
     if (n_views == 0) return BFF_OK;
     BFF_REQUIRE(mask_run_offs && view_mask_offs && maskbits, "bff_rle_to_maskbits: null pointer");   // run arrays may be empty (NULL)
-    dim3 grid((unsigned)ceil_div(n_pixels, (int64_t)kChunk * kChunksPerBand), (unsigned)n_views);
+    dim3 grid((unsigned)ceil_div(n_pixels, (int64_t)kWaveChunk * kWaveChunks * (kBlock / kWave)), (unsigned)n_views);
     const int64_t seg_words = ceil_div(ceil_div(n_pixels, 128), 32);
     if (segmap) {
         hipError_t e = hipMemsetAsync(segmap, 0, sizeof(uint32_t) * (size_t)n_views * seg_words, as_stream(stream));
