@@ -137,8 +137,8 @@ def bench_cosine(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", default="c2", choices=list(SHAPES) + ["c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -233,6 +233,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # the sweep kernel alone on the chip: a short strictly sequential loop after the timed region (in the
+    # pipelined loop it shares the GPU with the previous scene's back-half kernels)
+    seq_timers = KernelTimers()
+    if not args.no_pipeline:
+        was = args.no_pipeline
+        args.no_pipeline = True
+        run_steps(min(5, args.steps), seq_timers)
+        args.no_pipeline = was
+        fence()
+
     if rank == 0:
         ks = timers.summary()
         n_swept = ds.n_frames
@@ -257,7 +267,10 @@ def main():
                        "2 HIP streams: front half of scene i+1 overlaps the host-side back half of scene i"},
             "roofline": {"bound": "hbm", "kernel": "project_views_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": pv[2], "launches": pv[0]},
+                         "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": pv[2], "launches": pv[0],
+                         "alone_on_chip": (lambda t: {"avg_launch_ms": t, "achieved": abytes / (t * 1e-3) / 1e9,
+                                                      "frac": abytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS})(
+                             seq_timers.summary()["project_views"][2]) if not args.no_pipeline else None},
             "kernels_ms": {k: round(vv[2], 4) for k, vv in ks.items()},   # HIP-event spans (merge_components includes its read-back)
             "result": {"stage2_instances": int(res.rows.shape[0]),
                        "final_masks": int(fin[scene.scene_id].rows.shape[0]) if fin[scene.scene_id].rows is not None else 0,
