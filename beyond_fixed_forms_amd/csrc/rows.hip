@@ -623,7 +623,25 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
         pa[q] = ra >= 0 ? rows + (int64_t)ra * nw : nullptr;
         pb[q] = rb >= 0 ? rows + (int64_t)rb * nw : nullptr;
     }
+    // Staging is software pipelined: the words of stage g+1 are fetched into registers while stage g is
+    // combined out of LDS, so a stage costs max(load latency, compute) instead of their sum.
+    uint64_t ra[8], rb[8];
+    auto fetch = [&](int g) {
+        const int64_t w = (g + slot < cnt) ? (int64_t)clist[g + slot] * kCW + cw : nw;
+        const bool kin = w < nw;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            ra[q] = (kin && pa[q]) ? pa[q][w] : 0;
+            rb[q] = (kin && pb[q]) ? pb[q][w] : 0;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { sa[lk][lr + 8 * q] = ra[q]; sb[lk][lr + 8 * q] = rb[q]; }
+    };
+    constexpr int kStep = kKW / kCW;                               // chunks per stage
     constexpr int kSparse = 3;                                     // pair-list path: at most 3 pairs per thread
+    if (cnt) fetch(0);
     if (n_pairs <= kSparse * 256) {
         // few candidates: accumulate only those pairs (2 LDS reads per pair word)
         int pi[kSparse], pj[kSparse], accs[kSparse];
@@ -634,15 +652,10 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
             pi[q] = code >> 8; pj[q] = code & 255; accs[q] = 0;
         }
         const int n_mine = (n_pairs - tid + 255) / 256;            // pairs this thread really owns (<= kSparse)
-        for (int g = 0; g < cnt; g += kKW / kCW) {
-            const int64_t w = (g + slot < cnt) ? (int64_t)clist[g + slot] * kCW + cw : nw;
-            const bool kin = w < nw;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                sa[lk][lr + 8 * q] = (kin && pa[q]) ? pa[q][w] : 0;
-                sb[lk][lr + 8 * q] = (kin && pb[q]) ? pb[q][w] : 0;
-            }
+        for (int g = 0; g < cnt; g += kStep) {
+            stage();
             __syncthreads();
+            if (g + kStep < cnt) fetch(g + kStep);
 #pragma unroll
             for (int q = 0; q < kSparse; ++q)
                 if (q < n_mine) {
@@ -672,15 +685,10 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = 0;
-    for (int g = 0; g < cnt; g += kKW / kCW) {
-        const int64_t w = (g + slot < cnt) ? (int64_t)clist[g + slot] * kCW + cw : nw;
-        const bool kin = w < nw;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            sa[lk][lr + 8 * q] = (kin && pa[q]) ? pa[q][w] : 0;
-            sb[lk][lr + 8 * q] = (kin && pb[q]) ? pb[q][w] : 0;
-        }
+    for (int g = 0; g < cnt; g += kStep) {
+        stage();
         __syncthreads();
+        if (g + kStep < cnt) fetch(g + kStep);
 #pragma unroll 8
         for (int kk = 0; kk < kKW; ++kk) {
             uint64_t av[4], bv[4];
