@@ -787,15 +787,26 @@ __global__ __launch_bounds__(64) void group_conf_mean_kernel(const T *__restrict
 // merged into row i; pairs are visited in the reference's order (i ascending, j > i ascending) and the
 // and-not operations appended to `ops` ([0] = count, then (opcode, dst, src) triples).  One thread: K is
 // tens to a few hundred and the list order is the semantics.
-__global__ void overlap_ops_kernel(const int32_t *__restrict__ inter, const int32_t *__restrict__ size, int k,
-                                   int32_t *__restrict__ ops)
+constexpr int kOvlMax = 96;      // K x K flags staged in LDS when K <= 96 (9 KB); larger K reads global memory
+
+__global__ __launch_bounds__(256) void overlap_ops_kernel(const int32_t *__restrict__ inter,
+                                                           const int32_t *__restrict__ size, int k,
+                                                           int32_t *__restrict__ ops)
 {
-    if (blockIdx.x || threadIdx.x) return;
+    __shared__ uint8_t s_ovl[kOvlMax * kOvlMax];
+    __shared__ int s_size[kOvlMax];
+    const bool staged = k <= kOvlMax;
+    if (staged) {                                  // all threads stage, one thread replays the ordered loop
+        for (int i = threadIdx.x; i < k * k; i += blockDim.x) s_ovl[i] = inter[i] > 0;
+        for (int i = threadIdx.x; i < k; i += blockDim.x) s_size[i] = size[i];
+    }
+    __syncthreads();
+    if (threadIdx.x) return;
     int n = 0;
     for (int i = 0; i < k; ++i)
         for (int j = i + 1; j < k; ++j)
-            if (inter[(int64_t)i * k + j] > 0) {
-                const bool i_wins = size[i] > size[j];                 // ties: i loses (P:296-299)
+            if (staged ? s_ovl[i * k + j] : (inter[(int64_t)i * k + j] > 0)) {
+                const bool i_wins = (staged ? s_size[i] > s_size[j] : size[i] > size[j]);   // ties: i loses (P:296-299)
                 ops[1 + 3 * n] = 0;
                 ops[2 + 3 * n] = i_wins ? j : i;
                 ops[3 + 3 * n] = i_wins ? i : j;
@@ -1117,7 +1128,7 @@ extern "C" int bff_overlap_ops(const int32_t *inter, const int32_t *size, int32_
 {
     BFF_REQUIRE(k >= 0, "bff_overlap_ops: bad size");
     BFF_REQUIRE(ops && (k == 0 || (inter && size)), "bff_overlap_ops: null pointer");
-    overlap_ops_kernel<<<1, 64, 0, as_stream(stream)>>>(inter, size, k, ops);
+    overlap_ops_kernel<<<1, 256, 0, as_stream(stream)>>>(inter, size, k, ops);
     return launched("bff_overlap_ops");
 }
 

@@ -358,12 +358,13 @@ def test_resolve_overlaps_golden(lib):
         lib.resolve_overlaps(rows, torch.tensor(z[f"{case}.sizes"], dtype=torch.int32, device=DEV))
         assert np.array_equal(unpack(rows, n), gio.unpack_bool_rows(z[f"{case}.resolved"], n)), case
     rng = np.random.default_rng(9)
-    d = rng.random((23, 3000)) < 0.15
-    sizes = rng.integers(2, 6, 23)
-    exp = pref.resolve_overlaps(torch.from_numpy(d.copy()), [list(range(s)) for s in sizes]).numpy()
-    rows = pack_np(d)
-    lib.resolve_overlaps(rows, torch.tensor(sizes, dtype=torch.int32, device=DEV))
-    assert np.array_equal(unpack(rows, 3000), exp)
+    for k, p in ((23, 0.15), (110, 0.01)):         # 110 > 96 rows: the pair loop reads global memory
+        d = rng.random((k, 3000)) < p
+        sizes = rng.integers(2, 6, k)
+        exp = pref.resolve_overlaps(torch.from_numpy(d.copy()), [list(range(s)) for s in sizes]).numpy()
+        rows = pack_np(d)
+        lib.resolve_overlaps(rows, torch.tensor(sizes, dtype=torch.int32, device=DEV))
+        assert np.array_equal(unpack(rows, 3000), exp)
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 128, 10_001, 16_384 + 64, 200_000])
