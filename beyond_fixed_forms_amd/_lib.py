@@ -38,6 +38,7 @@ SIGNATURES = {
     "bff_unpack_rows": [_P, _I, _L, _L, _P, _P],
     "bff_pack_rows": [_P, _I, _L, _L, _P, _P],
     "bff_rle_to_rows": [_P, _P, _P, _I, _L, _L, _P, _P],
+    "bff_ids_to_rows": [_P, _L, _P, _I, _L, _P, _P],
     "bff_rle_count_runs": [_P, _I, _L, _P, _P],
     "bff_rle_encode_rows": [_P, _I, _L, _P, _L, _P, _P],
     "bff_ratio_keep": [_P, _P, _L, _F, _P, _I, _L, _P, _P],
@@ -316,6 +317,15 @@ def rle_to_rows(run_start, run_end, row_run_offs, n_points):
     nw = (n_points + 63) // 64
     rows = torch.empty((k, nw), dtype=i64, device=run_start.device)
     call("bff_rle_to_rows", _ptr(run_start, i32), _ptr(run_end, i32), _ptr(row_run_offs, i32), k, n_points, nw, _ptr(rows))
+    return rows
+
+
+def ids_to_rows(ids, values):
+    """int64 id per point (device) + int64 values (device) -> bit rows [len(values)][nw]: rows[v] = (ids == values[v])."""
+    n = ids.shape[0]
+    nw = (n + 63) // 64
+    rows = torch.empty((values.shape[0], nw), dtype=i64, device=ids.device)
+    call("bff_ids_to_rows", _ptr(ids, i64), n, _ptr(values, i64), values.shape[0], nw, _ptr(rows))
     return rows
 
 

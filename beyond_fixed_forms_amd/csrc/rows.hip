@@ -869,6 +869,16 @@ __global__ void pack_rows_kernel(const uint8_t *__restrict__ dense, int64_t n, i
     if (lane_id() == 0 && (p >> 6) < nw) rows[(int64_t)blockIdx.y * nw + (p >> 6)] = bal;
 }
 
+// ---- per-point ids -> bit rows (evaluation consumer, scannetv2_inst_eval.py:334: `gts == instance_id`) ---
+__global__ void ids_to_rows_kernel(const int64_t *__restrict__ ids, int64_t n, const int64_t *__restrict__ values,
+                                   int64_t nw, uint64_t *__restrict__ rows)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool bit = p < n && ids[p] == values[blockIdx.y];
+    const uint64_t bal = __ballot(bit);
+    if (lane_id() == 0 && (p >> 6) < nw) rows[(int64_t)blockIdx.y * nw + (p >> 6)] = bal;
+}
+
 // ---- 1-D RLE -> bit rows ----------------------------------------------------------------------
 __global__ void rle_to_rows_kernel(const int32_t *__restrict__ run_start, const int32_t *__restrict__ run_end,
                                    const int32_t *__restrict__ offs, int64_t n, int64_t nw, uint64_t *__restrict__ rows)
@@ -1213,4 +1223,16 @@ extern "C" int bff_rle_encode_rows(const uint64_t *rows, int32_t n_rows, int64_t
     rle_write_kernel<<<n_rows, 256, 0, as_stream(stream)>>>(rows, nw, run_offs, counts);
     rle_lengths_kernel<<<(unsigned)ceil_div(n_runs_total, 256), 256, 0, as_stream(stream)>>>(counts, n_runs_total);
     return launched("bff_rle_encode_rows");
+}
+
+extern "C" int bff_ids_to_rows(const int64_t *ids, int64_t n_points, const int64_t *values, int32_t n_values, int64_t nw,
+                               uint64_t *rows, void *stream)
+{
+    BFF_REQUIRE(n_points >= 0 && n_values >= 0 && nw == ceil_div(n_points, 64), "bff_ids_to_rows: bad sizes");
+    if (n_values == 0 || n_points == 0) return BFF_OK;
+    BFF_REQUIRE(ids && values && rows, "bff_ids_to_rows: null pointer");
+    BFF_LIMIT(n_values <= 65535, "bff_ids_to_rows: too many values");
+    dim3 grid((unsigned)ceil_div(nw * 64, 256), (unsigned)n_values);
+    ids_to_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(ids, n_points, values, nw, rows);
+    return launched("bff_ids_to_rows");
 }

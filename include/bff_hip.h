@@ -244,6 +244,13 @@ int bff_rle_count_runs(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t
 int bff_rle_encode_rows(const uint64_t *rows, int32_t n_rows, int64_t nw, const int64_t *run_offs,
                         int64_t n_runs_total, int64_t *counts, void *stream);
 
+/* SURVEY section 8f row 4 -- the consumer right after the path: ScanNet instance evaluation intersects every
+ * predicted mask with every ground-truth instance (`count_nonzero(logical_and(gts == instance_id, pred_mask))`,
+ * evaluation/eval/scannetv2_inst_eval.py:334).  bff_ids_to_rows turns the per-point id vector into one bit row
+ * per requested value (rows[v] bit p = ids[p] == values[v]); the intersections are then one bff_cross_popcount. */
+int bff_ids_to_rows(const int64_t *ids, int64_t n_points, const int64_t *values, int32_t n_values, int64_t nw,
+                    uint64_t *rows, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * a14/a15 -- point filters (P:512-583), kept entirely on the device.
  * bff_point_values: vals[n] = (float)masked[n] / ((float)viewed[n] + 1.0f) (P:571; IEEE float32), or

@@ -468,3 +468,25 @@ def test_cosine_gemm(lib, na, nb, dim):
     exp = (ai.double() @ bi.double().T) / (ai.double().norm(dim=1, keepdim=True) * bi.double().norm(dim=1, keepdim=True).T)
     ok = torch.isfinite(exp)
     assert (got[ok] - exp[ok]).abs().max().item() <= 1e-4
+
+
+def test_evaluation_overlaps_match_reference_formulas(lib):
+    """pred <-> GT overlap counting of assign_instances_for_scan (scannetv2_inst_eval.py:318-349): the numbers the
+    reference computes pair by pair with count_nonzero(logical_and(gts == id, pred_mask))."""
+    from beyond_fixed_forms_amd.evaluation import pred_gt_overlaps
+    rng = np.random.default_rng(12)
+    n, p_, g_ = 50_001, 17, 23
+    sem = rng.integers(0, 40, n)
+    ins = rng.integers(0, g_, n)
+    gts = sem * 1000 + ins + 1
+    gts[rng.random(n) < 0.1] = 0
+    ids = np.unique(gts)[1:][:g_]
+    pred = rng.random((p_, n)) < 0.05
+    pred[3] = False
+    bool_void = rng.random(n) < 0.2
+    inter, pc, gc, vi = pred_gt_overlaps(pack_np(pred), torch.from_numpy(gts), ids, bool_void)
+    for a in range(p_):
+        assert pc[a] == np.count_nonzero(pred[a]) and vi[a] == np.count_nonzero(np.logical_and(bool_void, pred[a]))
+        for b, gid in enumerate(ids):
+            assert inter[a, b] == np.count_nonzero(np.logical_and(gts == gid, pred[a]))
+    assert np.array_equal(gc, [(gts == gid).sum() for gid in ids])
