@@ -45,6 +45,8 @@ SIGNATURES = {
     "bff_point_values": [_P, _P, _L, _P, _P],
     "bff_select_unique_rank": [_P, _L, _D, _P, _P, _P, _P],
     "bff_cosine_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
+    "bff_sort_f32": [_P, _P, _L, _P, _P, _P],
+    "bff_argsort_i64": [_P, _P, _P, _I, _P, _P, _P],
     "bff_depth_from_u16": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P],
 }
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
@@ -348,6 +350,41 @@ def rows_to_rle(rows, n_points):
     return [dict(length=int(n_points), counts=flat[2 * offs[r]:2 * offs[r + 1]].copy()) for r in range(k)]
 
 
+_temp_bytes = {}
+
+
+def _sort_temp(kind, n, device, query):
+    """Device scratch for a library sort of n keys (size from the ABI's query call, cached per (kind, n))."""
+    key = (kind, n)
+    if key not in _temp_bytes:
+        need = ctypes.c_size_t(0)
+        query(ctypes.byref(need))
+        _temp_bytes[key] = int(need.value)
+    nbytes = _temp_bytes[key]
+    return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device), ctypes.c_size_t(nbytes)
+
+
+def sort_f32(vals):
+    """Ascending sort of a float32 device vector (rocPRIM radix sort behind bff_sort_f32)."""
+    n = vals.shape[0]
+    out = torch.empty_like(vals)
+    temp, nb = _sort_temp("f32", n, vals.device,
+                          lambda need: call("bff_sort_f32", None, None, n, None, need))
+    call("bff_sort_f32", _ptr(vals, f32), _ptr(out), n, _ptr(temp), ctypes.byref(nb))
+    return out
+
+
+def argsort_i64(keys):
+    """Stable ascending argsort of an int64 device vector -> int32 order (bff_argsort_i64)."""
+    n = keys.shape[0]
+    order = torch.empty(n, dtype=i32, device=keys.device)
+    scratch = torch.empty_like(keys)
+    temp, nb = _sort_temp("i64", n, keys.device,
+                          lambda need: call("bff_argsort_i64", None, None, None, n, None, need))
+    call("bff_argsort_i64", _ptr(keys, i64), _ptr(scratch), _ptr(order), n, _ptr(temp), ctypes.byref(nb))
+    return order
+
+
 def point_threshold(masked, viewed, fraction):
     """Device-resident threshold unique()[floor(fraction * n_unique)] of masked/(viewed+1) (or of masked when
     viewed is None), P:513-518 / 571-576.  Returns (thr f32[1], n_unique i32[1]) on the device."""
@@ -355,7 +392,7 @@ def point_threshold(masked, viewed, fraction):
     dev = masked.device
     vals = torch.empty(n, dtype=f32, device=dev)
     call("bff_point_values", _ptr(masked, i32), _ptr(viewed, i32), n, _ptr(vals))
-    vals = torch.sort(vals).values                      # library sort (plumbing), N floats
+    vals = sort_f32(vals)
     scratch = torch.empty(max(1, (n + 1023) // 1024), dtype=i32, device=dev)
     thr = torch.empty(1, dtype=f32, device=dev)
     n_unique = torch.empty(1, dtype=i32, device=dev)

@@ -215,10 +215,9 @@ def _projection_front(ds, cfg, debug_out, timers) -> _Front:
     # in the order (label, heavy-bin signature) so that a tile's rows occupy few chunks.
     with span(timers, "row_stats"):
         area, _mean_word, cmask, hist, sig = _lib.row_stats(rows)
-        order = torch.argsort(sig, stable=True)
-        if ds.n_label_ids > 1:                    # several label strings: cluster by label first
-            order = order[torch.argsort(ds.label_id[order], stable=True)]
-        order = order.to(torch.int32)
+        order = _lib.argsort_i64(sig)
+        if ds.n_label_ids > 1:                    # several label strings: cluster by label first (stable on top)
+            order = order[_lib.argsort_i64(ds.label_id[order.long()].to(torch.int64)).long()].contiguous()
     with span(timers, "merge_components"):
         fr.comp = _lib.merge_components(rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist)
     fr.area = area

@@ -21,6 +21,7 @@
 #ifndef BFF_HIP_H
 #define BFF_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -254,8 +255,8 @@ int bff_ids_to_rows(const int64_t *ids, int64_t n_points, const int64_t *values,
 /* ------------------------------------------------------------------------------------------
  * a14/a15 -- point filters (P:512-583), kept entirely on the device.
  * bff_point_values: vals[n] = (float)masked[n] / ((float)viewed[n] + 1.0f) (P:571; IEEE float32), or
- * (float)masked[n] when viewed == NULL (P:513).  The caller sorts vals ascending (a library sort, on its
- * side of the ABI), then bff_select_unique_rank writes *thr = distinct_values[floor(fraction * n_distinct)]
+ * (float)masked[n] when viewed == NULL (P:513).  The caller sorts vals ascending (bff_sort_f32), then
+ * bff_select_unique_rank writes *thr = distinct_values[floor(fraction * n_distinct)]
  * -- the reference's `x.unique()[math.floor(t * x.unique().shape[0])]` (P:516-518, 574-576; float64 product;
  * NaN when the index is out of range, where python raises IndexError) -- and *n_unique.  block_scratch:
  * int32 [ceil(n/1024)].
@@ -280,6 +281,16 @@ int bff_depth_from_u16(const uint16_t *src, int32_t n_frames, int32_t h_src, int
                        const int32_t *x0, const int32_t *x1, const float *ax,
                        const int32_t *y0, const int32_t *y1, const float *ay,
                        int32_t height, int32_t width, float depth_scale, float *dst, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Library sorts (rocPRIM radix sort) so that the ABI is self-sufficient.  Both follow the usual two-call
+ * protocol: temp == NULL -> only *temp_bytes is written (no launch); then call again with that much device
+ * scratch.  bff_sort_f32: keys_out = keys_in ascending (the input of bff_select_unique_rank).
+ * bff_argsort_i64: order_out = stable ascending argsort of int64 keys (ties keep index order), keys_scratch =
+ * int64 [n]; used to order the Gram tiles by row signature (and, stably on top, by label id). */
+int bff_sort_f32(const float *keys_in, float *keys_out, int64_t n, void *temp, size_t *temp_bytes, void *stream);
+int bff_argsort_i64(const int64_t *keys, int64_t *keys_scratch, int32_t *order_out, int32_t n, void *temp,
+                    size_t *temp_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a21/a24 -- cosine similarity GEMM on the matrix cores (MFMA f16 -> f32).

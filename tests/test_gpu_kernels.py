@@ -490,3 +490,15 @@ def test_evaluation_overlaps_match_reference_formulas(lib):
         for b, gid in enumerate(ids):
             assert inter[a, b] == np.count_nonzero(np.logical_and(gts == gid, pred[a]))
     assert np.array_equal(gc, [(gts == gid).sum() for gid in ids])
+
+
+@pytest.mark.parametrize("n", [1, 2, 1000, 200_003])
+def test_library_sorts(lib, n):
+    g = torch.Generator().manual_seed(n)
+    v = torch.rand(n, generator=g).mul(5).floor().div(3)            # many ties, non-negative like the ratios
+    v[0] = 0.0
+    got = lib.sort_f32(v.to(DEV)).cpu()
+    assert torch.equal(got, torch.sort(v).values)
+    keys = torch.randint(-5, 5, (n,), generator=g, dtype=torch.int64) * (1 << 40)
+    order = lib.argsort_i64(keys.to(DEV)).cpu().long()
+    assert torch.equal(order, torch.argsort(keys, stable=True))     # stable: ties keep index order
