@@ -13,7 +13,7 @@ from ctypes import c_double, c_float, c_int32, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbff_hip.so")
+LIB_PATH = os.environ.get("BFF_HIP_LIB") or os.path.join(_HERE, "lib", "libbff_hip.so")   # BFF_HIP_LIB: A/B builds
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 _P, _I, _L, _D, _F = c_void_p, c_int32, c_int64, c_double, c_float

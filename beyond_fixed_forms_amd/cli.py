@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import argparse
 import os
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
@@ -30,20 +31,31 @@ def projection_main(argv=None):
     cls = args.cls
     ckpt = read_scene_checkpoint("projection_2d_to_3d", cls)
     seg_dir = os.path.join(cfg.mask_2d_dir, cls)
-    for name in sorted(s for s in os.listdir(seg_dir) if s.endswith("_00.pth")):           # P:363
-        scene_id = name[:-4]
-        print("Working on", scene_id, "class", cls)
-        # BFF_DEPTH_ON_DEVICE=1: upload the 16-bit depth PNGs as they are, scale + resize them on the GPU
-        scene = load_scene(cfg, cls, scene_id, depth_on_device=os.environ.get("BFF_DEPTH_ON_DEVICE") == "1")
-        res = project_scene(scene, cfg, device="cuda", return_result=True)
-        if not res.debug.get("empty_form", False):
-            ckpt[scene_id] = True                                                         # P:580-581
-            write_scene_checkpoint("projection_2d_to_3d", cls, ckpt)
-        # BFF_SAVE_RLE=1 stores "ins" as RLE dicts (Open3DIS format; refinement.py and eval_scannet200.py:123-124
-        # read both forms) instead of the reference's dense bool matrix
-        out = res.to_rle_dict() if os.environ.get("BFF_SAVE_RLE") == "1" and not res.debug.get("empty_form") else res.to_dict()
-        save_result(out, cfg.mask_3d_dir, cls, scene_id)                                    # P:630-634
+    scene_ids = [s[:-4] for s in sorted(s for s in os.listdir(seg_dir) if s.endswith("_00.pth"))]   # P:363
+    # BFF_DEPTH_ON_DEVICE=1: upload the 16-bit depth PNGs as they are, scale + resize them on the GPU
+    on_dev = os.environ.get("BFF_DEPTH_ON_DEVICE") == "1"
+    # the files of scene k+1 (point cloud, ~300 depth PNGs, poses, the mask dict) are read by one background
+    # thread while the GPU works on scene k; a load error surfaces at that scene's turn, after scene k is saved
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        pending = pool.submit(load_scene, cfg, cls, scene_ids[0], depth_on_device=on_dev) if scene_ids else None
+        for k, scene_id in enumerate(scene_ids):
+            print("Working on", scene_id, "class", cls)
+            scene = pending.result()
+            pending = (pool.submit(load_scene, cfg, cls, scene_ids[k + 1], depth_on_device=on_dev)
+                       if k + 1 < len(scene_ids) else None)
+            _project_and_save(scene, scene_id, cfg, cls, ckpt)
     return 0
+
+
+def _project_and_save(scene, scene_id, cfg, cls, ckpt):
+    res = project_scene(scene, cfg, device="cuda", return_result=True)
+    if not res.debug.get("empty_form", False):
+        ckpt[scene_id] = True                                                             # P:580-581
+        write_scene_checkpoint("projection_2d_to_3d", cls, ckpt)
+    # BFF_SAVE_RLE=1 stores "ins" as RLE dicts (Open3DIS format; refinement.py and eval_scannet200.py:123-124
+    # read both forms) instead of the reference's dense bool matrix
+    out = res.to_rle_dict() if os.environ.get("BFF_SAVE_RLE") == "1" and not res.debug.get("empty_form") else res.to_dict()
+    save_result(out, cfg.mask_3d_dir, cls, scene_id)                                        # P:630-634
 
 
 def _clip_available():

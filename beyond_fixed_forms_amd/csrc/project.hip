@@ -7,9 +7,11 @@
 //                                         returns all masks of the frame)
 //   rows       u64 [n_rows][nw]          instance bit rows: a wave's 64 points are exactly one word,
 //                                         so __ballot() of "bit b set" IS the output word
-// Kernel shape: 256 threads = 4 waves own 1024 consecutive points (16 row words = 128 B per row,
-// one full line per row store), 4 points per thread kept in registers across the frames of the
-// block's frame tile; pose and intrinsics are wave-uniform (scalar loads / kernel arguments).
+// Kernel shape: 256 threads = 4 waves own 1024 consecutive points (16 row words = one 128-B line per row);
+// wave w owns the 4 consecutive words 4w..4w+3 of that line (its 32-B sector), 4 points per thread kept in
+// registers across the frames of the block's frame tile; pose and intrinsics are wave-uniform (scalar loads /
+// kernel arguments).  The frame loop has no block barrier: a wave transposes its ballots through a private LDS
+// slice and stores its own sector of every row of the frame.
 #include "common.h"
 
 namespace bff {
@@ -20,6 +22,8 @@ constexpr int kWordsPerBlock = (kBlock / kWave) * kPPT;   // 16 row words per bl
 constexpr int kPtsPerBlock = kWordsPerBlock * kWave;       // 1024
 
 struct Intrinsics { double k[9]; };
+
+__device__ __forceinline__ void lds_phase_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <typename WordT>
 __global__ __launch_bounds__(kBlock) void project_views_kernel(
@@ -33,19 +37,20 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
     uint64_t *__restrict__ rows, int64_t nw, int32_t *__restrict__ masked_count,
     int32_t *__restrict__ viewed_count)
 {
-    // [bit][word] staging of the block's row words; pitch 17 keeps lane-strided writes off one bank
-    __shared__ uint64_t stage[sizeof(WordT) * 8][kWordsPerBlock + 1];
+    // per wave: [bit][kPPT words] transposition buffer for the wave's sector of the frame's rows
+    __shared__ uint64_t stage_all[kBlock / kWave][sizeof(WordT) * 8][kPPT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t word0 = (int64_t)blockIdx.x * kWordsPerBlock;
+    const int64_t word0 = (int64_t)blockIdx.x * kWordsPerBlock + (int64_t)wave * kPPT;   // the wave's first word
     const int64_t hw = (int64_t)H * W;
+    uint64_t (*stage)[kPPT] = stage_all[wave];
 
     double px[kPPT], py[kPPT], pz[kPPT];
     bool valid[kPPT];
     int mcount[kPPT], vcount[kPPT];
 #pragma unroll
     for (int j = 0; j < kPPT; ++j) {
-        const int64_t n = (word0 + wave + 4 * j) * kWave + lane;
+        const int64_t n = (word0 + j) * kWave + lane;
         valid[j] = n < n_points;
         const int64_t m = valid[j] ? n : 0;
         px[j] = xyz[m];
@@ -62,67 +67,91 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
         const double *P = inv_pose + 16 * (int64_t)f;
         const float *dimg = depth + (int64_t)depth_index[f] * hw;
         const int mi = maskbits ? frame_mask[f] : -1;
-        const WordT *mimg = mi >= 0 ? maskbits + (int64_t)mi * hw : nullptr;
-        const uint32_t *smap = (segmap && mi >= 0) ? segmap + (int64_t)mi * seg_words : nullptr;
-        const int nm = mimg ? frame_nmask[f] : 0;
+        const bool has_masks = mi >= 0;
+        const WordT *mimg = has_masks ? maskbits + (int64_t)mi * hw : nullptr;
+        const uint32_t *smap = (segmap && has_masks) ? segmap + (int64_t)mi * seg_words : nullptr;
+        const int nm = has_masks ? frame_nmask[f] : 0;
         const bool count_viewed = (frame_flags[f] & 1) != 0;
+        // Three phases per frame so that a thread's gathers are all in flight together (the sweep is bound by
+        // memory latency x concurrency, not by issue): (1) geometry of the 4 points, (2) depth + segment-bitmap
+        // gathers of every in-bounds point, (3) mask-word gathers of every visible point in a masked segment.
+        int pix[kPPT];
+        double cz[kPPT];
 #pragma unroll
         for (int j = 0; j < kPPT; ++j) {
             // k-ascending fma chains from +0.0: bit-identical to the reference's dgemm (header contract)
             const double cx = fma(P[3], 1.0, fma(P[2], pz[j], fma(P[1], py[j], fma(P[0], px[j], 0.0))));
             const double cy = fma(P[7], 1.0, fma(P[6], pz[j], fma(P[5], py[j], fma(P[4], px[j], 0.0))));
-            const double cz = fma(P[11], 1.0, fma(P[10], pz[j], fma(P[9], py[j], fma(P[8], px[j], 0.0))));
-            const double p0 = fma(K.k[2], cz, fma(K.k[1], cy, fma(K.k[0], cx, 0.0)));
-            const double p1 = fma(K.k[5], cz, fma(K.k[4], cy, fma(K.k[3], cx, 0.0)));
-            const double u = rint(p0 / cz);
-            const double v = rint(p1 / cz);
+            cz[j] = fma(P[11], 1.0, fma(P[10], pz[j], fma(P[9], py[j], fma(P[8], px[j], 0.0))));
+            const double p0 = fma(K.k[2], cz[j], fma(K.k[1], cy, fma(K.k[0], cx, 0.0)));
+            const double p1 = fma(K.k[5], cz[j], fma(K.k[4], cy, fma(K.k[3], cx, 0.0)));
+            const double u = rint(p0 / cz[j]);
+            const double v = rint(p1 / cz[j]);
             const bool inb = valid[j] && (u >= 0.0) && (u < dW) && (v >= 0.0) && (v < dH);   // NaN fails
-            bool vis = false;
-            WordT w = 0;
-            if (inb) {
-                const int64_t pix = (int64_t)(int)v * W + (int)u;
-                const float d = dimg[pix];
-                vis = (d != 0.0f) && (fabs(cz - (double)d) < thresh);
-                if (vis && mimg) {
-                    // segments without any mask pixel were never written by the decoder: consult its bitmap
-                    const bool has = !smap || ((smap[pix >> 12] >> ((pix >> 7) & 31)) & 1);
-                    if (has) w = mimg[pix];
-                }
-            }
-            if (count_viewed) vcount[j] += vis ? 1 : 0;
-            if (mimg) {
-                mcount[j] += (sizeof(WordT) == 8) ? __popcll((uint64_t)w) : __popc((uint32_t)w);
-                // lane b collects the ballot of bit b.  Most waves see no mask at all in a given frame, and
-                // the others only a few of its masks: OR the words across the wave and visit the set bits.
-                uint64_t mine = 0;
-                if (__ballot(w != 0)) {                     // wave-uniform
-                    WordT present = w;
+            pix[j] = inb ? (int)v * W + (int)u : -1;       // H*W < 2^31 (checked by the entry point)
+        }
+        float dval[kPPT];
+        uint32_t sbits[kPPT];
 #pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) present |= __shfl_xor(present, d);
-                    while (present) {
-                        const int b = (sizeof(WordT) == 8) ? __ffsll((unsigned long long)present) - 1
-                                                           : __ffs((unsigned)present) - 1;
-                        present &= present - 1;
-                        const uint64_t bal = __ballot((w >> b) & 1);
-                        if (lane == b) mine = bal;
-                    }
-                }
-                if (lane < nm) stage[lane][wave + 4 * j] = mine;
+        for (int j = 0; j < kPPT; ++j) {
+            dval[j] = 0.0f;
+            sbits[j] = 0xffffffffu;
+            if (pix[j] >= 0) {
+                dval[j] = dimg[pix[j]];
+                // segments without any mask pixel were never written by the decoder: consult its bitmap
+                if (smap) sbits[j] = smap[pix[j] >> 12];
             }
         }
-        if (mimg) {                                        // block-uniform
-            __syncthreads();
+        bool vis[kPPT];
+        WordT wv[kPPT];
+#pragma unroll
+        for (int j = 0; j < kPPT; ++j) {
+            vis[j] = (pix[j] >= 0) && (dval[j] != 0.0f) && (fabs(cz[j] - (double)dval[j]) < thresh);
+            wv[j] = 0;
+            if (vis[j] && mimg && ((sbits[j] >> ((pix[j] >> 7) & 31)) & 1)) wv[j] = mimg[pix[j]];
+        }
+        WordT present = 0;
+#pragma unroll
+        for (int j = 0; j < kPPT; ++j) {
+            if (count_viewed) vcount[j] += vis[j] ? 1 : 0;
+            mcount[j] += (sizeof(WordT) == 8) ? __popcll((uint64_t)wv[j]) : __popc((uint32_t)wv[j]);
+            present |= wv[j];
+        }
+        if (has_masks) {                                   // wave-uniform
+            // the wave's 32-B sector (kPPT words) of each of the frame's nm rows: lane -> (row lane/4 + 16 i,
+            // word lane%4).  Most waves see no mask at all in a given frame: the rows were zeroed by the entry point.
             const int64_t rb = frame_rowbase[f];
-            const int wd = tid & (kWordsPerBlock - 1);
-            if (word0 + wd < nw)
-                for (int b = tid / kWordsPerBlock; b < nm; b += kBlock / kWordsPerBlock)
-                    rows[(rb + b) * nw + word0 + wd] = stage[b][wd];
-            __syncthreads();
+            const int wd = lane & (kPPT - 1);
+            const bool in_rows = word0 + wd < nw;
+            if (__ballot(present != 0)) {
+                // lane b collects the ballots of bit b: OR the words across the wave, visit the set bits only
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) present |= __shfl_xor(present, d);
+                uint64_t mine[kPPT] = {};
+                while (present) {
+                    const int b = (sizeof(WordT) == 8) ? __ffsll((unsigned long long)present) - 1
+                                                       : __ffs((unsigned)present) - 1;
+                    present &= present - 1;
+#pragma unroll
+                    for (int j = 0; j < kPPT; ++j) {
+                        const uint64_t bal = __ballot((wv[j] >> b) & 1);
+                        if (lane == b) mine[j] = bal;
+                    }
+                }
+                if (lane < (int)(sizeof(WordT) * 8)) {
+#pragma unroll
+                    for (int j = 0; j < kPPT; ++j) stage[lane][j] = mine[j];
+                }
+                lds_phase_fence();                         // wave-private slice: LDS ops complete in issue order
+                for (int b = lane / kPPT; b < nm; b += kWave / kPPT)
+                    if (in_rows) rows[(rb + b) * nw + word0 + wd] = stage[b][wd];
+                lds_phase_fence();                         // reads done before the next frame's writes
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < kPPT; ++j) {
-        const int64_t n = (word0 + wave + 4 * j) * kWave + lane;
+        const int64_t n = (word0 + j) * kWave + lane;
         if (valid[j]) {
             if (masked_count && mcount[j]) atomicAdd(masked_count + n, mcount[j]);
             if (viewed_count && vcount[j]) atomicAdd(viewed_count + n, vcount[j]);
@@ -140,8 +169,6 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
 // are not written when a segment bitmap is requested.  HBM traffic = at most one write of the image.
 constexpr int kWaveChunk = 512;              // pixels per wave chunk (4 + 4 per lane)
 constexpr int kWaveChunks = 32;              // chunks per wave band (16384 pixels)
-
-__device__ __forceinline__ void lds_phase_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <typename WordT>
 __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
@@ -297,6 +324,10 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
     if (maskbits) {
         BFF_REQUIRE(word_bits == 32 || word_bits == 64, "bff_project_views: word_bits must be 32 or 64");
         BFF_REQUIRE(frame_mask && frame_rowbase && frame_nmask && rows && n_rows >= 0, "bff_project_views: mask frames need row outputs");
+    }
+    if (maskbits && n_rows > 0) {       // the kernel stores only the sectors in which a wave saw a mask bit
+        hipError_t e = hipMemsetAsync(rows, 0, sizeof(uint64_t) * (size_t)n_rows * (size_t)nw, as_stream(stream));
+        if (e != hipSuccess) return fail((int)e, "bff_project_views: memset: %s", hipGetErrorString(e));
     }
     Intrinsics K;
     for (int i = 0; i < 9; ++i) K.k[i] = cam_intr_host[i];

@@ -83,8 +83,8 @@ int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const 
  *   frame_rowbase int32 [n_frames]: first instance row of the frame (row = rowbase + bit)
  *   frame_nmask  int32 [n_frames]: number of masks (bits) of the frame, 0..word_bits
  *   frame_flags  int32 [n_frames]: bit0 = add visibility to viewed_count (P:567)
- *   rows         uint64 [n_rows][nw] instance bit rows, written (not accumulated) for every frame
- *                with a mask image: row (rowbase+b), all nw words                        (a6, a8)
+ *   rows         uint64 [n_rows][nw] instance bit rows: zeroed by this call (all n_rows rows), then row
+ *                (rowbase+b) receives the points of mask b of every frame with a mask image   (a6, a8)
  *   masked_count int32 [n_points], += number of masks of the frame containing the visible point
  *                (P:459-461 adds 1 per mask, not per view); may be NULL
  *   viewed_count int32 [n_points], += visibility for frames with flag bit0; may be NULL
