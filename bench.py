@@ -184,11 +184,23 @@ def main():
     timers = KernelTimers()
     streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
 
+    host = {"front_issue_s": 0.0, "back_s": 0.0}     # host wall time per half (back includes its sync waits)
+
     def front(i, tm=None):
+        t = time.perf_counter()
         with torch.cuda.stream(streams[i % 2]):
-            return projection_front(ds, cfg, timers=tm)
+            fr = projection_front(ds, cfg, timers=tm)
+        host["front_issue_s"] += time.perf_counter() - t
+        return fr
 
     def back(i, fr):
+        t = time.perf_counter()
+        try:
+            return _back(i, fr)
+        finally:
+            host["back_s"] += time.perf_counter() - t
+
+    def _back(i, fr):
         with torch.cuda.stream(streams[i % 2]):
             res = projection_back(fr)
             fin = refine_class([(scene.scene_id, stage1, res)], cfg, QUERY, sim, dev, exchange_sims=exchange)
@@ -224,10 +236,15 @@ def main():
             torch.cuda.synchronize()
 
     fence()
+    host.update(front_issue_s=0.0, back_s=0.0)
+    _lib.sync_wait_s = 0.0
     t0 = time.perf_counter()
     res, fin, gathered = run_steps(args.steps, timers)
     fence()
     elapsed = time.perf_counter() - t0
+    host_ms = {"front_issue": round(host["front_issue_s"] / args.steps * 1e3, 4),
+               "back": round(host["back_s"] / args.steps * 1e3, 4),
+               "of_which_waiting_for_gpu": round(_lib.sync_wait_s / args.steps * 1e3, 4)}
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -271,6 +288,7 @@ def main():
                          "alone_on_chip": (lambda t: {"avg_launch_ms": t, "achieved": abytes / (t * 1e-3) / 1e9,
                                                       "frac": abytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS})(
                              seq_timers.summary()["project_views"][2]) if not args.no_pipeline else None},
+            "host_ms": host_ms,      # wall time of the host thread per step: issuing the front half, the back half, and the part of the back half spent blocked on the GPU
             "kernels_ms": {k: round(vv[2], 4) for k, vv in ks.items()},   # HIP-event spans (merge_components includes its read-back)
             "result": {"stage2_instances": int(res.rows.shape[0]),
                        "final_masks": int(fin[scene.scene_id].rows.shape[0]) if fin[scene.scene_id].rows is not None else 0,

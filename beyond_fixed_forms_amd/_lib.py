@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time
 from ctypes import c_double, c_float, c_int32, c_int64, c_void_p
 
 import torch
@@ -21,15 +22,16 @@ _P, _I, _L, _D, _F = c_void_p, c_int32, c_int64, c_double, c_float
 # name -> argument ctypes (every entry point returns int); mirrors include/bff_hip.h one to one
 SIGNATURES = {
     "bff_rle_to_maskbits": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P],
-    "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P],
+    "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P],
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
-    "bff_row_stats": [_P, _I, _L, _P, _P, _P, _P, _P, _P],
+    "bff_row_stats": [_P, _I, _L, _P, _P, _P, _I, _P, _P, _P],
     "bff_merge_components": [_P, _I, _L, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P],
     "bff_merge_adjacency": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "bff_permute_bits": [_P, _I, _L, _P, _L, _L, _P, _P],
     "bff_components_round": [_P, _I, _P, _P, _P, _P],
-    "bff_or_reduce_groups": [_P, _L, _P, _P, _I, _I, _P, _P],
+    "bff_or_reduce_groups": [_P, _L, _P, _P, _I, _I, _P, _P, _I, _P, _P],
+    "bff_resolve_overlaps": [_P, _I, _L, _P, _P, _P, _P, _P, _P],
     "bff_group_conf_mean": [_P, _I, _P, _P, _I, _P, _P],
     "bff_apply_row_ops": [_P, _L, _P, _I, _P],
     "bff_overlap_ops": [_P, _P, _I, _P, _P],
@@ -50,7 +52,7 @@ SIGNATURES = {
     "bff_depth_from_u16": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P],
 }
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
-         "bff_chunk_mask_words": (c_int32, [c_int64]),
+         "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P])}
 ABI_VERSION = 1
 
@@ -150,7 +152,7 @@ def rle_to_maskbits(run_start, run_end, mask_run_offs, view_mask_offs, n_views, 
 
 def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, height, width, depth_thresh,
                   maskbits, word_bits, frame_mask, frame_rowbase, frame_nmask, frame_flags,
-                  rows, masked_count, viewed_count, segmap=None):
+                  rows, masked_count, viewed_count, segmap=None, chunk_mask=None):
     k = (c_double * 9)(*[float(v) for v in cam_intr.reshape(-1)])
     n_frames = inv_pose.shape[0]
     nw = (n_points + 63) // 64
@@ -158,7 +160,8 @@ def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, hei
          ctypes.cast(k, c_void_p), n_frames, _ptr(depth, f32), _ptr(depth_index, i32), height, width,
          float(depth_thresh), _ptr(maskbits), _ptr(segmap, i32), word_bits, _ptr(frame_mask, i32), _ptr(frame_rowbase, i32),
          _ptr(frame_nmask, i32), _ptr(frame_flags, i32), _ptr(rows, i64),
-         0 if rows is None else rows.shape[0], nw, _ptr(masked_count, i32), _ptr(viewed_count, i32))
+         0 if rows is None else rows.shape[0], nw, _ptr(chunk_mask, i64), _ptr(masked_count, i32),
+         _ptr(viewed_count, i32))
 
 
 def popcount_rows(rows, idx=None):
@@ -176,17 +179,24 @@ def cross_popcount(a, b, ia=None, ib=None):
     return out
 
 
-def row_stats(rows):
-    """-> (area i32 [R], mean_word i32 [R], chunk_mask i64 [R][mw], hist i32 [R][64], signature i64 [R])."""
+def chunk_mask_buffer(n_rows, nw, device):
+    """Uninitialised chunk occupancy masks i64 [n_rows][mw] (bff_project_views zeroes and fills them)."""
+    return torch.empty((n_rows, max(load().bff_chunk_mask_words(nw), 1)), dtype=i64, device=device)
+
+
+def row_stats(rows, cmask=None):
+    """-> (area i32 [R], mean_word i32 [R], chunk_mask i64 [R][mw], hist i32 [R][64], signature i64 [R]).
+    cmask given (from project_views): only the flagged chunks are read."""
     n = rows.shape[0]
-    mw = load().bff_chunk_mask_words(rows.shape[1])
+    given = cmask is not None
     area = torch.empty(n, dtype=i32, device=rows.device)
     mean_word = torch.empty(n, dtype=i32, device=rows.device)
-    cmask = torch.empty((n, max(mw, 1)), dtype=i64, device=rows.device)
+    if not given:
+        cmask = chunk_mask_buffer(n, rows.shape[1], rows.device)
     hist = torch.empty((n, 64), dtype=i32, device=rows.device)
     sig = torch.empty(n, dtype=i64, device=rows.device)
-    call("bff_row_stats", _ptr(rows, i64), n, rows.shape[1], _ptr(area), _ptr(mean_word), _ptr(cmask), _ptr(hist),
-         _ptr(sig))
+    call("bff_row_stats", _ptr(rows, i64), n, rows.shape[1], _ptr(area), _ptr(mean_word), _ptr(cmask, i64),
+         1 if given else 0, _ptr(hist), _ptr(sig))
     return area, mean_word, cmask, hist, sig
 
 
@@ -254,12 +264,20 @@ def components(adj, max_rounds=10_000):
     raise RuntimeError("bff_components_round did not converge")
 
 
-def or_reduce_groups(rows, group_offs, members, max_group_size):
+def or_reduce_groups(rows, group_offs, members, max_group_size, conf=None):
+    """out[g] = OR of the member rows.  conf given (float16/float32 per row): also returns the groups' sequential
+    confidence means (group_conf_mean), computed by extra blocks of the same launch."""
     k = group_offs.shape[0] - 1
     out = torch.empty((k, rows.shape[1]), dtype=i64, device=rows.device)
+    mean = None
+    if conf is not None:
+        if conf.dtype not in (torch.float16, torch.float32):
+            raise TypeError(f"confidences must be float16 or float32, got {conf.dtype}")
+        mean = torch.empty(k, dtype=conf.dtype, device=conf.device)
     call("bff_or_reduce_groups", _ptr(rows, i64), rows.shape[1], _ptr(group_offs, i32), _ptr(members, i32), k,
-         int(max_group_size), _ptr(out))
-    return out
+         int(max_group_size), _ptr(out), _ptr(conf), 1 if (conf is not None and conf.dtype == torch.float16) else 0,
+         _ptr(mean))
+    return out if conf is None else (out, mean)
 
 
 def group_conf_mean(conf, group_offs, members):
@@ -286,6 +304,27 @@ def resolve_overlaps(rows, sizes):
     ops = torch.empty(1 + 3 * (k * (k - 1) // 2), dtype=i32, device=rows.device)
     call("bff_overlap_ops", _ptr(inter, i32), _ptr(sizes, i32), k, _ptr(ops))
     call("bff_apply_row_ops", _ptr(rows, i64), rows.shape[1], _ptr(ops), -1)
+
+
+def resolve_overlaps_filtered(rows, sizes, keep):
+    """solve_overlapping (P:277-301), `&= keep` (P:595) and the popcounts before / after (P:592, 596) in two
+    launches (intersections, then one fused pass) -> (before, after) int32 device tensors.  More than
+    bff_resolve_overlaps_max_rows() rows: the same through the separate entry points."""
+    k = rows.shape[0]
+    inter = cross_popcount(rows, rows)
+    if k <= load().bff_resolve_overlaps_max_rows():
+        before = torch.empty(k, dtype=i32, device=rows.device)
+        after = torch.empty(k, dtype=i32, device=rows.device)
+        call("bff_resolve_overlaps", _ptr(rows, i64), k, rows.shape[1], _ptr(inter, i32), _ptr(sizes, i32),
+             _ptr(keep, i64), _ptr(before), _ptr(after))
+        return before, after
+    before = inter.diagonal().contiguous()
+    if k >= 2:
+        ops = torch.empty(1 + 3 * (k * (k - 1) // 2), dtype=i32, device=rows.device)
+        call("bff_overlap_ops", _ptr(inter, i32), _ptr(sizes, i32), k, _ptr(ops))
+        call("bff_apply_row_ops", _ptr(rows, i64), rows.shape[1], _ptr(ops), -1)
+    and_rows(rows, keep)
+    return before, popcount_rows(rows)
 
 
 def and_rows(rows, keep):
@@ -421,6 +460,39 @@ def host_component_csr(comp, has_self_loop, min_members):
     return offs[:k + 1], members[:offs[k]], sizes[:k], int(n_void.value)
 
 
+_up_ring = {}             # (dtype, capacity) -> [buffers, events, next]
+
+
+def upload(data, dtype, device):
+    """Small host array / list -> device tensor without blocking the host: the values go through a ring of
+    pinned staging buffers and an asynchronous copy on the current stream (a pageable `.to(device)` would stall
+    the host until everything queued on the stream before it has finished)."""
+    t = data if torch.is_tensor(data) else torch.as_tensor(data)
+    t = t.to(dtype).reshape(-1) if t.dtype != dtype else t.reshape(-1)
+    shape = tuple(data.shape) if hasattr(data, "shape") else (t.numel(),)
+    n = t.numel()
+    if torch.device(device).type != "cuda" or n == 0:
+        return t.reshape(shape).to(device)
+    cap = max(64, 1 << (n - 1).bit_length())
+    ring = _up_ring.get((dtype, cap))
+    if ring is None:
+        ring = _up_ring[(dtype, cap)] = [[torch.empty(cap, dtype=dtype, pin_memory=True) for _ in range(8)],
+                                         [None] * 8, 0]
+    k = ring[2]
+    ring[2] = (k + 1) % 8
+    if ring[1][k] is not None:
+        ring[1][k].synchronize()               # the copy that last used this buffer (8 uploads ago) is long done
+    buf = ring[0][k][:n]
+    buf.copy_(t)
+    out = buf.to(device, non_blocking=True)
+    ev = ring[1][k] = ring[1][k] or torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    return out.reshape(shape)
+
+
+sync_wait_s = 0.0          # wall time spent blocked in fetch()'s synchronisations (a host-side profile counter)
+
+
 def fetch(*tensors):
     """Device tensors -> numpy arrays with ONE stream synchronisation (async copies into reused pinned
     staging buffers; the returned arrays are copies, so the staging can be reused by the next call)."""
@@ -434,7 +506,10 @@ def fetch(*tensors):
             buf = _pinned[key] = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
         buf.copy_(t.reshape(-1), non_blocking=True)
         host.append((buf, t.shape))
+    global sync_wait_s
+    t0 = time.perf_counter()
     (_stream_cache[1] if _stream_cache is not None else torch.cuda.current_stream()).synchronize()
+    sync_wait_s += time.perf_counter() - t0
     return [b.numpy().reshape(shape).copy() for b, shape in host]
 
 

@@ -12,6 +12,7 @@
 namespace bff {
 
 constexpr int kWave = 64;   // CDNA wavefront
+constexpr int kCW = 8;      // words per row chunk (512 points): granularity of the rows' occupancy masks
 
 char *err_buf();
 

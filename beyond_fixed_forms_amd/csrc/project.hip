@@ -34,8 +34,8 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
     const int32_t *__restrict__ frame_mask,
     const int32_t *__restrict__ frame_rowbase, const int32_t *__restrict__ frame_nmask,
     const int32_t *__restrict__ frame_flags,
-    uint64_t *__restrict__ rows, int64_t nw, int32_t *__restrict__ masked_count,
-    int32_t *__restrict__ viewed_count)
+    uint64_t *__restrict__ rows, int64_t nw, uint64_t *__restrict__ chunk_mask, int mw,
+    int32_t *__restrict__ masked_count, int32_t *__restrict__ viewed_count)
 {
     // per wave: [bit][kPPT words] transposition buffer for the wave's sector of the frame's rows
     __shared__ uint64_t stage_all[kBlock / kWave][sizeof(WordT) * 8][kPPT];
@@ -122,7 +122,6 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
             // word lane%4).  Most waves see no mask at all in a given frame: the rows were zeroed by the entry point.
             const int64_t rb = frame_rowbase[f];
             const int wd = lane & (kPPT - 1);
-            const bool in_rows = word0 + wd < nw;
             if (__ballot(present != 0)) {
                 // lane b collects the ballots of bit b: OR the words across the wave, visit the set bits only
 #pragma unroll
@@ -143,8 +142,19 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
                     for (int j = 0; j < kPPT; ++j) stage[lane][j] = mine[j];
                 }
                 lds_phase_fence();                         // wave-private slice: LDS ops complete in issue order
-                for (int b = lane / kPPT; b < nm; b += kWave / kPPT)
-                    if (in_rows) rows[(rb + b) * nw + word0 + wd] = stage[b][wd];
+                // only the rows that received a bit are stored (their 32-B sector), and flagged in the rows'
+                // chunk occupancy masks so that later passes visit nothing else
+                const int chunk = (int)(word0 / kCW);
+                for (int b0 = 0; b0 < nm; b0 += kWave / kPPT) {        // wave-uniform trip count
+                    const int b = b0 + lane / kPPT;
+                    const uint64_t v = b < nm ? stage[b][wd] : 0;
+                    const uint64_t nz = __ballot(v != 0);
+                    if ((nz >> (lane & ~(kPPT - 1))) & ((1u << kPPT) - 1)) {
+                        if (word0 + wd < nw) rows[(rb + b) * nw + word0 + wd] = v;     // nw need not be a multiple of 4
+                        if (chunk_mask && wd == 0)
+                            atomicOr((unsigned long long *)(chunk_mask + (rb + b) * mw + (chunk >> 6)), 1ull << (chunk & 63));
+                    }
+                }
                 lds_phase_fence();                         // reads done before the next frame's writes
             }
         }
@@ -161,14 +171,36 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // 2-D RLE -> mask words, wave-synchronous.  Every wave owns a band of kWaveChunks x 512 pixels of one
-// mask-view and a private 512-word LDS slice; lane b < n_masks keeps mask b's run cursor (current + next
-// run in registers).  Per 512-pixel chunk the runs enter LDS as XOR toggles at their clipped start and end,
-// an XOR prefix scan (4 + 4 words per lane, wave shuffles) turns toggles into coverage, and the chunk is
-// written with two fully coalesced 1-KiB (u32) stores.  There is no block barrier: waves never wait for each
+// mask-view and a private 1024-word LDS slice; lane b < n_masks keeps mask b's run cursor (current + next
+// run in registers).  Per 1024-pixel chunk the runs enter LDS as XOR toggles at their clipped start and end,
+// an XOR prefix scan (4 words per lane in each of 4 sub-blocks, DPP wave scans) turns toggles into coverage, and
+// the chunk is written with four fully coalesced 1-KiB (u32) stores.  There is no block barrier: waves never wait for each
 // other, LDS accesses of one wave complete in issue order.  Segments of 128 pixels without any mask pixel
 // are not written when a segment bitmap is requested.  HBM traffic = at most one write of the image.
-constexpr int kWaveChunk = 512;              // pixels per wave chunk (4 + 4 per lane)
-constexpr int kWaveChunks = 32;              // chunks per wave band (16384 pixels)
+constexpr int kSub = 4;                      // 256-word sub-blocks per chunk; a lane owns 4 consecutive words of each
+constexpr int kWaveChunk = kSub * 256;       // pixels per wave chunk
+constexpr int kWaveChunks = 16384 / kWaveChunk;   // chunks per wave band (16384 pixels)
+
+// Inclusive XOR prefix over the 64 lanes of a wave in six DPP steps (row shifts 1, 2, 4, 8 inside each 16-lane
+// row, then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2-3): register-to-register, no LDS
+// round trips (a __shfl_up ladder is six dependent ds_bpermute latencies).
+__device__ __forceinline__ uint32_t wave_xor_scan(uint32_t v)
+{
+#define BFF_DPP_XOR(ctrl, rows) v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xF, false)
+    BFF_DPP_XOR(0x111, 0xF);    // row_shr:1
+    BFF_DPP_XOR(0x112, 0xF);    // row_shr:2
+    BFF_DPP_XOR(0x114, 0xF);    // row_shr:4
+    BFF_DPP_XOR(0x118, 0xF);    // row_shr:8
+    BFF_DPP_XOR(0x142, 0xA);    // row_bcast:15 -> rows 1 and 3
+    BFF_DPP_XOR(0x143, 0xC);    // row_bcast:31 -> rows 2 and 3
+#undef BFF_DPP_XOR
+    return v;
+}
+
+__device__ __forceinline__ uint64_t wave_xor_scan(uint64_t v)
+{
+    return (uint64_t)wave_xor_scan((uint32_t)v) | ((uint64_t)wave_xor_scan((uint32_t)(v >> 32)) << 32);
+}
 
 template <typename WordT>
 __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
@@ -177,43 +209,52 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
     int64_t n_pixels, WordT *__restrict__ maskbits, uint32_t *__restrict__ segmap, int64_t seg_words)
 {
     __shared__ WordT lds[kBlock / kWave][kWaveChunk];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: band and chunk bounds stay in SGPRs
     WordT *bits = lds[wave];
     const int v = blockIdx.y;
     const int g0 = view_mask_offs[v];
     const int nm = view_mask_offs[v + 1] - g0;
-    const int64_t band0 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kWaveChunk * kWaveChunks;
-    if (band0 >= n_pixels) return;                   // wave-uniform
+    const int64_t band64 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kWaveChunk * kWaveChunks;
+    if (band64 >= n_pixels) return;                  // wave-uniform
+    const int band0 = (int)band64, npx = (int)n_pixels;               // n_pixels < 2^31 (checked by the entry point)
     WordT *img = maskbits + (int64_t)v * n_pixels;
 
-    constexpr int64_t kNone = INT64_MAX;
+    constexpr int kNone = INT32_MAX;                 // > every pixel index
     int cur = 0, hi = 0;
-    int64_t rs = kNone, re = kNone, ns = kNone, ne = kNone;
+    int rs = kNone, re = kNone, ns = kNone, ne = kNone;
     if (lane < nm) {
         int lo = mask_run_offs[g0 + lane];
         hi = mask_run_offs[g0 + lane + 1];
         int r = hi;                                   // first run with end > band0
         while (lo < r) {
             const int mid = (lo + r) >> 1;
-            if ((int64_t)run_end[mid] > band0) r = mid; else lo = mid + 1;
+            if (run_end[mid] > band0) r = mid; else lo = mid + 1;
         }
         cur = r;
         if (cur < hi) { rs = run_start[cur]; re = run_end[cur]; }
         if (cur + 1 < hi) { ns = run_start[cur + 1]; ne = run_end[cur + 1]; }
     }
-    constexpr int kHalf = kWaveChunk / 2, kQ = 4;     // lane owns words [4l, 4l+4) of each 256-word half
+    constexpr int kHalf = 256, kQ = 4;                // lane owns words [4l, 4l+4) of each 256-word sub-block
 #pragma unroll
-    for (int k = 0; k < kQ; ++k) { bits[lane * kQ + k] = 0; bits[kHalf + lane * kQ + k] = 0; }
+    for (int h = 0; h < kSub; ++h)
+#pragma unroll
+        for (int k = 0; k < kQ; ++k) bits[h * kHalf + lane * kQ + k] = 0;
     lds_phase_fence();
+    const WordT bit = (WordT)1 << (lane & (int)(sizeof(WordT) * 8 - 1));
+    uint32_t *smap = segmap ? segmap + (int64_t)v * seg_words : nullptr;
     for (int c = 0; c < kWaveChunks; ++c) {
-        const int64_t c0 = band0 + (int64_t)c * kWaveChunk;
-        if (c0 >= n_pixels) break;
-        const int64_t c1 = min(c0 + kWaveChunk, n_pixels);
+        const int c0 = band0 + c * kWaveChunk;        // scalar
+        if (c0 >= npx) break;
+        const bool whole = npx - c0 >= kWaveChunk;    // every chunk but the image's last one
+        const int c1 = whole ? c0 + kWaveChunk : npx;
+        // no mask has a run that reaches into this chunk (idle lanes hold kNone): all its words are zero, and
+        // with a segment bitmap zero segments are not written at all
+        if (smap && !__ballot(rs < c1)) continue;
         if (lane < nm) {
-            const WordT bit = (WordT)1 << lane;
             while (rs < c1) {
-                atomicXor(&bits[(int)(max(rs, c0) - c0)], bit);
-                if (re < c1) atomicXor(&bits[(int)(re - c0)], bit);
+                atomicXor(&bits[max(rs, c0) - c0], bit);
+                if (re < c1) atomicXor(&bits[re - c0], bit);
                 if (re > c1) break;                   // run continues into the next chunk
                 ++cur;
                 rs = ns; re = ne;
@@ -221,9 +262,9 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
             }
         }
         lds_phase_fence();                            // toggles of all lanes are in LDS
-        WordT loc[2][kQ], tot[2];
+        WordT loc[kSub][kQ], tot[kSub];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < kSub; ++h) {
             WordT acc = 0;
 #pragma unroll
             for (int k = 0; k < kQ; ++k) {
@@ -234,46 +275,44 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
             tot[h] = acc;
         }
         lds_phase_fence();                            // re-zeroing is ordered before the next chunk's toggles
-        WordT incl[2] = {tot[0], tot[1]};
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const WordT u0 = __shfl_up(incl[0], d), u1 = __shfl_up(incl[1], d);
-            if (lane >= d) { incl[0] ^= u0; incl[1] ^= u1; }
-        }
-        const WordT half0_total = __shfl(incl[0], kWave - 1);
-        const WordT carry0 = incl[0] ^ tot[0];                       // exclusive prefix within the half
-        const WordT carry1 = incl[1] ^ tot[1] ^ half0_total;         // second half continues the first
+        WordT carry_in = 0;                                          // XOR of the sub-blocks before this one
         using Vec = __attribute__((ext_vector_type(4))) uint32_t;
+        WordT *img_c = img + c0;                                     // scalar base; the lane offset never changes
+        uint32_t seg_bits = 0;                                       // scalar: non-zero 128-pixel segments of the chunk
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const WordT carry = h ? carry1 : carry0;
-            const int64_t p0 = c0 + h * kHalf + (int64_t)lane * kQ;
+        for (int h = 0; h < kSub; ++h) {
+            const WordT incl = wave_xor_scan(tot[h]);
+            const WordT carry = incl ^ tot[h] ^ carry_in;            // exclusive prefix, continuing the chunk
+            carry_in ^= __shfl(incl, kWave - 1);
             WordT outv[kQ];
             WordT any = 0;
 #pragma unroll
             for (int k = 0; k < kQ; ++k) { outv[k] = loc[h][k] ^ carry; any |= outv[k]; }
-            if (segmap) {
+            bool store = true;
+            if (smap) {
                 // 128-pixel segments = 32 consecutive lanes: all-zero segments are not stored at all, the
                 // sweep learns from the bitmap (one bit per segment) that there is nothing to gather there
                 const uint64_t nz = __ballot(any != 0);
-                const uint32_t half_nz = (uint32_t)(nz >> (lane & 32));
-                if ((lane & 31) == 0 && p0 < c1) {
-                    const int64_t seg = p0 >> 7;
-                    if (half_nz) atomicOr(segmap + (int64_t)v * seg_words + (seg >> 5), 1u << (seg & 31));
-                }
-                if (!half_nz) continue;
+                const uint32_t lo = (uint32_t)nz, up = (uint32_t)(nz >> 32);
+                seg_bits |= ((lo ? 1u : 0u) | (up ? 2u : 0u)) << (2 * h);
+                store = (lane < 32 ? lo : up) != 0;
             }
-            if (p0 + kQ <= c1) {
-                const Vec *src = reinterpret_cast<const Vec *>(outv);
-                Vec *dst = reinterpret_cast<Vec *>(img + p0);      // chunk starts are multiples of 512 words
+            const int q = h * kHalf + lane * kQ;                     // word of the chunk
+            if (store) {
+                if (whole || c0 + q + kQ <= c1) {     // `whole` is scalar: the common case has no per-lane bounds test
+                    const Vec *src = reinterpret_cast<const Vec *>(outv);
+                    Vec *dst = reinterpret_cast<Vec *>(img_c + q);             // chunk starts are multiples of 1024 words
 #pragma unroll
-                for (int k = 0; k < (int)(kQ * sizeof(WordT) / 16); ++k) dst[k] = src[k];
-            } else {
+                    for (int k = 0; k < (int)(kQ * sizeof(WordT) / 16); ++k) dst[k] = src[k];
+                } else {
 #pragma unroll
-                for (int k = 0; k < kQ; ++k)
-                    if (p0 + k < c1) img[p0 + k] = outv[k];
+                    for (int k = 0; k < kQ; ++k)
+                        if (c0 + q + k < c1) img_c[q + k] = outv[k];
+                }
             }
         }
+        // a chunk's 8 segments are 8 consecutive bits of one bitmap word (chunks start at multiples of 1024 pixels)
+        if (smap && seg_bits && lane == 0) atomicOr(smap + (c0 >> 12), seg_bits << ((c0 >> 7) & 31));
     }
 }
 
@@ -312,7 +351,7 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
                                  const void *maskbits, const uint32_t *segmap, int32_t word_bits,
                                  const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
                                  const int32_t *frame_flags,
-                                 uint64_t *rows, int64_t n_rows, int64_t nw,
+                                 uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
                                  int32_t *masked_count, int32_t *viewed_count, void *stream)
 {
     BFF_REQUIRE(n_points >= 0 && n_pad >= n_points && n_frames >= 0, "bff_project_views: bad sizes");
@@ -329,6 +368,11 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
         hipError_t e = hipMemsetAsync(rows, 0, sizeof(uint64_t) * (size_t)n_rows * (size_t)nw, as_stream(stream));
         if (e != hipSuccess) return fail((int)e, "bff_project_views: memset: %s", hipGetErrorString(e));
     }
+    const int mw = (int)ceil_div(ceil_div(nw, kCW), 64);
+    if (maskbits && n_rows > 0 && chunk_mask) {
+        hipError_t e = hipMemsetAsync(chunk_mask, 0, sizeof(uint64_t) * (size_t)n_rows * (size_t)mw, as_stream(stream));
+        if (e != hipSuccess) return fail((int)e, "bff_project_views: memset: %s", hipGetErrorString(e));
+    }
     Intrinsics K;
     for (int i = 0; i < 9; ++i) K.k[i] = cam_intr_host[i];
     const int64_t gx = ceil_div(n_points, kPtsPerBlock);
@@ -340,11 +384,11 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
         project_views_kernel<uint32_t><<<grid, kBlock, 0, as_stream(stream)>>>(
             xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
             (const uint32_t *)maskbits, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
-            masked_count, viewed_count);
+            chunk_mask, mw, masked_count, viewed_count);
     else
         project_views_kernel<uint64_t><<<grid, kBlock, 0, as_stream(stream)>>>(
             xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
             (const uint64_t *)maskbits, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
-            masked_count, viewed_count);
+            chunk_mask, mw, masked_count, viewed_count);
     return launched("bff_project_views");
 }

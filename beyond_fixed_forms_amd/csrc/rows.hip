@@ -107,7 +107,6 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
 // ---- row statistics for the block-sparse Gram -------------------------------------------------
 // Per row: popcount, occupancy mask over chunks of kCW words, and the mean word position of its set
 // bits (sort key that brings rows covering the same region of the -- spatially sorted -- cloud together).
-constexpr int kCW = 8;        // words per chunk (512 points)
 constexpr int kBins = 64;     // histogram bins per row (each ceil(nw/64) words wide)
 
 __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restrict__ rows, int64_t nw, int mw,
@@ -156,6 +155,54 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restri
         const unsigned long long t = psum[0] + psum[1] + psum[2] + psum[3];
         area[r] = a;
         mean_word[r] = a ? (int32_t)(t / (unsigned long long)a) : 0x7fffffff;   // empty rows sort last
+    }
+}
+
+// The same statistics when the rows' chunk masks are already known (the sweep flags the chunks it stores
+// into): one wave per row, lane l takes the flagged chunks l, l+64, ... and reads only those 64 bytes.
+__global__ __launch_bounds__(256) void row_stats_sparse_kernel(const uint64_t *__restrict__ rows, int n_rows, int64_t nw,
+                                                                int mw, int bin_words, int32_t *__restrict__ area,
+                                                                int32_t *__restrict__ mean_word,
+                                                                const uint64_t *__restrict__ cmask,
+                                                                uint32_t *__restrict__ hist, int64_t *__restrict__ signature)
+{
+    __shared__ uint32_t s_hist[4][kBins];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= n_rows) return;                                   // wave-uniform; no block barrier below
+    const uint64_t *row = rows + (int64_t)r * nw;
+    uint32_t *hs = s_hist[wave];
+    hs[lane] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int s = 0;
+    unsigned long long ws = 0;
+    for (int i = 0; i < mw; ++i) {
+        const uint64_t m = cmask[(int64_t)r * mw + i];
+        if ((m >> lane) & 1) {
+            const int64_t w0 = ((int64_t)i * 64 + lane) * kCW;
+#pragma unroll
+            for (int k = 0; k < kCW; ++k) {
+                const int64_t w = w0 + k;
+                const uint64_t v = w < nw ? row[w] : 0;
+                if (v) {
+                    const int pc = popc64(v);
+                    atomicAdd(&hs[(int)(w / bin_words)], (uint32_t)pc);
+                    s += pc;
+                    ws += (unsigned long long)pc * (unsigned long long)w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { s += __shfl_xor(s, d); ws += __shfl_xor(ws, d); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint32_t hv = hs[lane];
+    hist[(int64_t)r * kBins + lane] = hv;
+    const uint64_t heavy = __ballot((uint64_t)hv * 100 >= (uint64_t)s * 15 && s > 0);
+    if (lane == 0) {
+        signature[r] = s ? (int64_t)(__brevll(heavy) >> 1) : 0x7fffffffffffffffll;
+        area[r] = s;
+        mean_word[r] = s ? (int32_t)(ws / (unsigned long long)s) : 0x7fffffff;
     }
 }
 
@@ -733,12 +780,55 @@ __global__ void permute_bits_kernel(const uint64_t *__restrict__ in, int64_t nw_
 // ---- group OR / confidence mean ---------------------------------------------------------------
 constexpr int kOrSplit = 32;      // members per block along z
 
-__global__ void or_reduce_groups_kernel(const uint64_t *__restrict__ rows, int64_t nw,
-                                        const int32_t *__restrict__ offs, const int32_t *__restrict__ members,
-                                        uint64_t *__restrict__ out)
+// Sequential mean of one group's confidences by the first wave of the calling block: all its lanes gather
+// 1024 confidences into LDS at once (the gathers are the slow part), then lane 0 runs the strictly sequential
+// sum the reference defines (P:225) -- one rounding in the confidence dtype per step.
+template <typename T>
+__device__ __forceinline__ void group_conf_mean_wave(const T *__restrict__ conf, const int32_t *__restrict__ offs,
+                                                     const int32_t *__restrict__ members, int g, T *__restrict__ mean,
+                                                     T *stage /* LDS [1024] */)
 {
-    // blockIdx.z takes members [z*32, z*32+32) of group blockIdx.y; partial ORs meet in the zeroed output
-    const int g = blockIdx.y;
+    const int lane = threadIdx.x;                  // callers pass threads 0..63 only
+    const int lo = offs[g], hi = offs[g + 1];
+    T s;
+    if constexpr (sizeof(T) == 2) s = __float2half_rn(0.0f); else s = 0.0f;
+    for (int base = lo; base < hi; base += 1024) {
+        const int cnt = min(1024, hi - base);
+        for (int k = lane; k < cnt; k += kWave) stage[k] = conf[members[base + k]];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // one wave: LDS ops complete in issue order
+        if (lane == 0) {
+#pragma unroll 8
+            for (int k = 0; k < cnt; ++k) {
+                if constexpr (sizeof(T) == 2) s = __hadd(s, stage[k]);        // one f16 rounding per step
+                else s = __fadd_rn(s, stage[k]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (lane == 0) {
+        if constexpr (sizeof(T) == 2) mean[g] = __float2half_rn(__fdiv_rn(__half2float(s), (float)(hi - lo)));
+        else mean[g] = __fdiv_rn(s, (float)(hi - lo));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void or_reduce_groups_kernel(const uint64_t *__restrict__ rows, int64_t nw,
+                                                                const int32_t *__restrict__ offs,
+                                                                const int32_t *__restrict__ members, int n_groups,
+                                                                uint64_t *__restrict__ out, const T *__restrict__ conf,
+                                                                T *__restrict__ mean)
+{
+    // blockIdx.z takes members [z*32, z*32+32) of group blockIdx.y; partial ORs meet in the zeroed output.
+    // Blocks with blockIdx.y == 0 when conf != NULL (groups then start at y = 1) do not OR anything: their first wave
+    // computes the sequential confidence means of groups blockIdx.x, blockIdx.x + gridDim.x, ... so that the
+    // longest chain of dependent additions runs beside the OR instead of after it.
+    __shared__ T stage[1024];
+    const int g = conf ? (int)blockIdx.y - 1 : (int)blockIdx.y;     // slice y = 0 is dispatched first
+    if (g < 0) {
+        if (blockIdx.z == 0 && threadIdx.x < kWave)
+            for (int q = blockIdx.x; q < n_groups; q += gridDim.x) group_conf_mean_wave(conf, offs, members, q, mean, stage);
+        return;
+    }
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lo = offs[g] + blockIdx.z * kOrSplit, hi = min(offs[g + 1], lo + kOrSplit);
     if (w >= nw || lo >= hi) return;
@@ -755,30 +845,8 @@ __global__ __launch_bounds__(64) void group_conf_mean_kernel(const T *__restrict
                                                              const int32_t *__restrict__ members, int n_groups,
                                                              T *__restrict__ mean)
 {
-    // one wave per group: all lanes gather 1024 confidences into LDS at once (the gathers are the slow
-    // part), then lane 0 runs the strictly sequential sum the reference defines (P:225)
     __shared__ T stage[1024];
-    const int g = blockIdx.x;
-    const int lo = offs[g], hi = offs[g + 1];
-    T s;
-    if constexpr (sizeof(T) == 2) s = __float2half_rn(0.0f); else s = 0.0f;
-    for (int base = lo; base < hi; base += 1024) {
-        const int cnt = min(1024, hi - base);
-        for (int k = threadIdx.x; k < cnt; k += 64) stage[k] = conf[members[base + k]];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll 8
-            for (int k = 0; k < cnt; ++k) {
-                if constexpr (sizeof(T) == 2) s = __hadd(s, stage[k]);        // one f16 rounding per step
-                else s = __fadd_rn(s, stage[k]);
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if constexpr (sizeof(T) == 2) mean[g] = __float2half_rn(__fdiv_rn(__half2float(s), (float)(hi - lo)));
-        else mean[g] = __fdiv_rn(s, (float)(hi - lo));
-    }
+    group_conf_mean_wave(conf, offs, members, (int)blockIdx.x, mean, stage);
 }
 
 // ---- row programs -----------------------------------------------------------------------------
@@ -826,6 +894,65 @@ __global__ void apply_row_ops_kernel(uint64_t *__restrict__ rows, int64_t nw, co
         const uint64_t sv = rows[(int64_t)s * nw + w];
         uint64_t *dp = rows + (int64_t)d * nw + w;
         *dp = op == 0 ? (*dp & ~sv) : op == 1 ? (*dp | sv) : sv;
+    }
+}
+
+// solve_overlapping (P:285-299) + the point filter (P:595) + both popcounts (P:592, 596) in one pass for K <= 64
+// rows.  One wave per 64 word columns: the K words of a column live in LDS, every thread replays the reference's
+// ordered pair loop on its own column (the pair flags come from the intersections BEFORE any edit, P:289-292),
+// ANDs with `keep`, writes the column back and the wave adds the columns' popcounts to after[].
+constexpr int kFuseMax = 64;
+
+__global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restrict__ rows, int64_t nw, int k,
+                                                              const int32_t *__restrict__ inter,
+                                                              const int32_t *__restrict__ size,
+                                                              const uint64_t *__restrict__ keep,
+                                                              int32_t *__restrict__ before, int32_t *__restrict__ after)
+{
+    constexpr int kPitch = kWave + 1;                        // column- and row-wise LDS accesses both conflict-free
+    __shared__ unsigned long long s_mask[kFuseMax];          // row i -> rows j > i that overlap it
+    __shared__ int s_size[kFuseMax];
+    extern __shared__ uint64_t s_dyn[];
+    uint64_t *s_col = s_dyn;                                 // [k][kPitch]
+    int32_t *s_int = reinterpret_cast<int32_t *>(s_dyn + (size_t)k * kPitch);   // [k][k]
+    const int t = threadIdx.x;
+    const int64_t w = (int64_t)blockIdx.x * kWave + t;
+    // independent loads, several in flight: the intersections, then this thread's word of every row
+#pragma unroll 8
+    for (int q = t; q < k * k; q += kWave) s_int[q] = inter[q];
+#pragma unroll 8
+    for (int r = 0; r < k; ++r) s_col[r * kPitch + t] = w < nw ? rows[(int64_t)r * nw + w] : 0;
+    if (t < k) s_size[t] = size[t];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // single wave: its LDS ops complete in order
+    for (int i = 0; i < k; ++i) {
+        const int v = t < k ? s_int[i * k + t] : 0;
+        const unsigned long long m = __ballot(v > 0 && t > i);
+        if (t == 0) s_mask[i] = m;
+        if (t == i && blockIdx.x == 0) before[i] = v;         // popcount of the row before any edit (P:592)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int i = 0; i < k; ++i) {
+        unsigned long long m = s_mask[i];                     // wave-uniform
+        while (m) {
+            const int j = __ffsll(m) - 1;
+            m &= m - 1;
+            const bool i_wins = s_size[i] > s_size[j];        // ties: i loses (P:296-299)
+            const int d = i_wins ? j : i, sr = i_wins ? i : j;
+            s_col[d * kPitch + t] &= ~s_col[sr * kPitch + t];
+        }
+    }
+    const uint64_t kp = keep ? (w < nw ? keep[w] : 0) : ~0ull;
+    for (int r = 0; r < k; ++r) {
+        const uint64_t v = s_col[r * kPitch + t] & kp;
+        s_col[r * kPitch + t] = v;
+        if (w < nw) rows[(int64_t)r * nw + w] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (t < k) {                                              // lane r adds up row r over the block's 64 columns
+        int pc = 0;
+#pragma unroll 8
+        for (int c = 0; c < kWave; ++c) pc += popc64(s_col[t * kPitch + c]);
+        if (pc) atomicAdd(after + t, pc);
     }
 }
 
@@ -1012,7 +1139,8 @@ extern "C" int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t 
 }
 
 extern "C" int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *area, int32_t *mean_word,
-                             uint64_t *chunk_mask, uint32_t *hist, int64_t *signature, void *stream)
+                             uint64_t *chunk_mask, int32_t chunk_mask_given, uint32_t *hist, int64_t *signature,
+                             void *stream)
 {
     BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_row_stats: bad sizes");
     if (n_rows == 0) return BFF_OK;
@@ -1020,6 +1148,12 @@ extern "C" int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, i
     const int n_chunks = (int)ceil_div(nw, kCW);
     BFF_LIMIT(n_chunks <= kMaxChunks, "bff_row_stats: more than %d chunks (N > %d points)", kMaxChunks, kMaxChunks * kCW * 64);
     const int mw = (int)ceil_div(n_chunks, 64);
+    static_assert(kBins == kWave, "row_stats_sparse_kernel: one histogram bin per lane");
+    if (chunk_mask_given) {
+        row_stats_sparse_kernel<<<(unsigned)ceil_div(n_rows, 4), 256, 0, as_stream(stream)>>>(
+            rows, n_rows, nw, mw, (int)ceil_div(nw > 0 ? nw : 1, kBins), area, mean_word, chunk_mask, hist, signature);
+        return launched("bff_row_stats");
+    }
     row_stats_kernel<<<n_rows, 256, mw * sizeof(uint64_t), as_stream(stream)>>>(
         rows, nw, mw, (int)ceil_div(nw > 0 ? nw : 1, kBins), area, mean_word, chunk_mask, hist, signature);
     return launched("bff_row_stats");
@@ -1102,19 +1236,28 @@ extern "C" int bff_permute_bits(const uint64_t *rows_in, int32_t n_rows, int64_t
 
 extern "C" int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int32_t *group_offs,
                                     const int32_t *members, int32_t n_groups, int32_t max_group_size,
-                                    uint64_t *out, void *stream)
+                                    uint64_t *out, const void *conf, int32_t conf_dtype, void *conf_mean,
+                                    void *stream)
 {
     BFF_REQUIRE(n_groups >= 0 && nw >= 0, "bff_or_reduce_groups: bad sizes");
-    if (n_groups == 0 || nw == 0) return BFF_OK;
+    if (n_groups == 0) return BFF_OK;
     BFF_REQUIRE(rows && group_offs && members && out, "bff_or_reduce_groups: null pointer");
+    BFF_REQUIRE((conf == nullptr) == (conf_mean == nullptr) && (conf_dtype == 0 || conf_dtype == 1),
+                "bff_or_reduce_groups: conf and conf_mean go together, dtype 0 (f32) or 1 (f16)");
+    if (nw == 0 && !conf) return BFF_OK;
     // z covers the largest group in slices of kOrSplit members; max_group_size is a host-known bound
     const int nz = (int)ceil_div(max_group_size > 0 ? max_group_size : 1, kOrSplit);
-    if (nz > 1) {
+    if (nz > 1 && nw > 0) {
         hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t) * (size_t)n_groups * nw, as_stream(stream));
         if (e != hipSuccess) return fail((int)e, "bff_or_reduce_groups: memset: %s", hipGetErrorString(e));
     }
-    dim3 grid((unsigned)ceil_div(nw, 256), (unsigned)n_groups, (unsigned)nz);
-    or_reduce_groups_kernel<<<grid, 256, 0, as_stream(stream)>>>(rows, nw, group_offs, members, out);
+    dim3 grid((unsigned)ceil_div(nw > 0 ? nw : 1, 256), (unsigned)(n_groups + (conf ? 1 : 0)), (unsigned)nz);
+    if (conf_dtype == 1)
+        or_reduce_groups_kernel<__half><<<grid, 256, 0, as_stream(stream)>>>(rows, nw, group_offs, members, n_groups, out,
+                                                                            (const __half *)conf, (__half *)conf_mean);
+    else
+        or_reduce_groups_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(rows, nw, group_offs, members, n_groups, out,
+                                                                           (const float *)conf, (float *)conf_mean);
     return launched("bff_or_reduce_groups");
 }
 
@@ -1141,6 +1284,23 @@ extern "C" int bff_overlap_ops(const int32_t *inter, const int32_t *size, int32_
     overlap_ops_kernel<<<1, 256, 0, as_stream(stream)>>>(inter, size, k, ops);
     return launched("bff_overlap_ops");
 }
+
+extern "C" int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const int32_t *inter, const int32_t *size,
+                                    const uint64_t *keep, int32_t *before, int32_t *after, void *stream)
+{
+    BFF_REQUIRE(k >= 0 && nw >= 0, "bff_resolve_overlaps: bad sizes");
+    BFF_LIMIT(k <= kFuseMax, "bff_resolve_overlaps: more than %d rows (use bff_overlap_ops + bff_apply_row_ops)", kFuseMax);
+    if (k == 0) return BFF_OK;
+    BFF_REQUIRE(rows && inter && size && before && after, "bff_resolve_overlaps: null pointer");
+    hipError_t e = hipMemsetAsync(after, 0, sizeof(int32_t) * (size_t)k, as_stream(stream));
+    if (e != hipSuccess) return fail((int)e, "bff_resolve_overlaps: memset: %s", hipGetErrorString(e));
+    resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave,
+                              sizeof(uint64_t) * (size_t)k * (kWave + 1) + sizeof(int32_t) * (size_t)k * k,
+                              as_stream(stream)>>>(rows, nw, k, inter, size, keep, before, after);
+    return launched("bff_resolve_overlaps");
+}
+
+extern "C" int bff_resolve_overlaps_max_rows(void) { return kFuseMax; }
 
 extern "C" int bff_apply_row_ops(uint64_t *rows, int64_t nw, const int32_t *ops, int32_t n_ops, void *stream)
 {

@@ -33,6 +33,7 @@ class Stage2Result:
     final_class: List[str]
     groups: list                  # indices of the raw 2-D masks merged into each *pre-filter* instance
     debug: dict
+    conf_host: Optional[torch.Tensor] = None      # `conf` again, on the host (read back with the last fetch)
 
     @property
     def empty(self):
@@ -195,11 +196,13 @@ def _projection_front(ds, cfg, debug_out, timers) -> _Front:
     masked = fr.masked = torch.zeros(n, dtype=torch.int32, device=dev)                          # P:402
     viewed = fr.viewed = torch.zeros(n, dtype=torch.int32, device=dev) if do_ratio else None    # P:537
     n_frames = ds.n_frames if do_ratio else ds.n_mask_frames
+    # the sweep flags, per row, the 512-point chunks it stores into: the later passes read nothing else
+    cmask_in = _lib.chunk_mask_buffer(ds.n_rows, nw, dev) if (ds.n_rows and n_mviews) else None
     with span(timers, "project_views"):
         _lib.project_views(ds.xyz, n, ds.inv_pose[:n_frames], ds.cam_intr, ds.depth, ds.depth_index, ds.height,
                            ds.width, DEPTH_THRESH, maskbits if n_mviews else None, ds.word_bits, ds.frame_mask,
                            ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows if ds.n_rows else None,
-                           masked, viewed, segmap if n_mviews else None)
+                           masked, viewed, segmap if n_mviews else None, cmask_in)
     del maskbits
     # a14/a15: point filter (P:512-583), entirely on the device: the threshold never visits the host
     if cfg.if_occurance_threshold or do_ratio:
@@ -214,7 +217,7 @@ def _projection_front(ds, cfg, debug_out, timers) -> _Front:
     # a9-a12: components of the IoU / label merge graph (P:100-146, 250-274) in one pass.  Rows are tiled
     # in the order (label, heavy-bin signature) so that a tile's rows occupy few chunks.
     with span(timers, "row_stats"):
-        area, _mean_word, cmask, hist, sig = _lib.row_stats(rows)
+        area, _mean_word, cmask, hist, sig = _lib.row_stats(rows, cmask_in)
         order = _lib.argsort_i64(sig)
         if ds.n_label_ids > 1:                    # several label strings: cluster by label first (stable on top)
             order = order[_lib.argsort_i64(ds.label_id[order.long()].to(torch.int64)).long()].contiguous()
@@ -291,9 +294,8 @@ def _projection_back(fr: _Front, timers, phases) -> Stage2Result:
         return _empty(ds, dbg)
 
     # a13: OR of member rows, sequential mean of confidences, label of the first member (P:214-226)
-    offs_d, members_d = torch.from_numpy(offs).to(dev), torch.from_numpy(members).to(dev)
-    agg = _lib.or_reduce_groups(rows, offs_d, members_d, int(sizes.max()))
-    conf = _lib.group_conf_mean(ds.conf, offs_d, members_d)
+    offs_d, members_d = _lib.upload(offs, torch.int32, dev), _lib.upload(members, torch.int32, dev)
+    agg, conf = _lib.or_reduce_groups(rows, offs_d, members_d, int(sizes.max()), ds.conf)
     first_member = members[offs[:-1]]
     agg_labels = [ds.labels[i] for i in first_member]
     if not debug_out:
@@ -302,34 +304,35 @@ def _projection_back(fr: _Front, timers, phases) -> Stage2Result:
     mark("grouping+or_reduce")
 
     # a16: overlap resolution (P:592-596), decided and applied on the device
-    before = _lib.popcount_rows(agg)                                                # P:592
     if size_list is None:
-        _lib.resolve_overlaps(agg, torch.from_numpy(sizes).to(dev))                 # P:594
+        before, after = _lib.resolve_overlaps_filtered(agg, _lib.upload(sizes, torch.int32, dev), keep)   # P:592-596
     else:           # sizes indexed like mask_indeces_to_be_merged, which still holds the empty components
+        before = _lib.popcount_rows(agg)                                            # P:592
         inter = _lib.cross_popcount(agg, agg).cpu().numpy()
         k = agg.shape[0]
         ops = [(0, j, i) if size_list[i] > size_list[j] else (0, i, j)
                for i in range(k) for j in range(i + 1, k) if inter[i, j] > 0]
         if ops:
-            _lib.apply_row_ops(agg, torch.tensor(ops, dtype=torch.int32).to(dev))
-    _lib.and_rows(agg, keep)                                                        # P:595
-    after = _lib.popcount_rows(agg)                                                 # P:596
+            _lib.apply_row_ops(agg, _lib.upload(np.asarray(ops, dtype=np.int32), torch.int32, dev))
+        _lib.and_rows(agg, keep)                                                    # P:595
+        after = _lib.popcount_rows(agg)                                             # P:596
     mark("overlap")
 
     # a17: size filters with the reference's dtype promotion (int64 vs python scalars, P:601-606)
-    before_h, after_h = _lib.fetch(before, after)                                   # the second (last) sync
+    before_h, after_h, conf_h = _lib.fetch(before, after, conf)                     # the second (last) sync
     before_t, after_t = torch.from_numpy(before_h).to(torch.int64), torch.from_numpy(after_h).to(torch.int64)
     keep_rows = (after_t > cfg.remove_small_masks) & (after_t > cfg.remove_filtered_masks * before_t)
     idx = torch.nonzero(keep_rows).view(-1).to(torch.int32)
     dbg.update(before=before_t, after=after_t, keep=keep_rows)
-    idx_d = idx.to(dev)
+    idx_d = _lib.upload(idx, torch.int32, dev)
     out_rows = unsorted(_lib.gather_rows(agg, idx_d)) if idx.numel() else agg[:0]
     out_conf = conf[idx_d.long()]
+    conf_host = torch.from_numpy(conf_h)[idx.long()]                # the same values, already on the host
     out_labels = [c for c, kk in zip(agg_labels, keep_rows.tolist()) if kk]
     mark("size_filter+output")
     lazy = _LazyGroups(offs, members) if groups is None else groups
     dbg["groups"] = lazy
-    return Stage2Result(ds.scene_id, n, out_rows, out_conf, out_labels, lazy, dbg)
+    return Stage2Result(ds.scene_id, n, out_rows, out_conf, out_labels, lazy, dbg, conf_host)
 
 
 def project_scene(scene, cfg, device="cuda", return_result: bool = False, debug_out: bool = False):

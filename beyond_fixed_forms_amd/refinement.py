@@ -91,7 +91,7 @@ class TextSimilarity:
 def _stage2_rows(stage2, n_points, device):
     """Stage-2 result (Stage2Result or the reference's dict) -> (bit rows [K][nw], conf (K,) on CPU)."""
     if isinstance(stage2, Stage2Result):
-        return stage2.rows, stage2.conf.cpu()
+        return stage2.rows, stage2.conf_host if stage2.conf_host is not None else stage2.conf.cpu()
     conf = stage2["conf"]
     if len(conf) == 0:                                                              # R:196
         return torch.zeros((0, (n_points + 63) // 64), dtype=torch.int64, device=device), torch.as_tensor(conf).cpu()
@@ -158,7 +158,7 @@ class _SceneState:
 def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: TextSimilarity, device) -> _SceneState:
     s1, n, s1_labels = _stage1_rows(stage1, device)
     s2, conf2 = _stage2_rows(stage2, n, device)
-    i32 = lambda lst: torch.tensor(lst, dtype=torch.int32, device=device)
+    i32 = lambda lst: _lib.upload(np.asarray(lst, dtype=np.int32), torch.int32, device)
     if len(conf2) == 0:                                                             # R:196-205
         other = [i for i, lab in enumerate(s1_labels) if lab == query_us]
         return _SceneState(scene_id, n, [], [], None, None, [], _lib.gather_rows(s1, i32(other)) if other else s1[:0])
@@ -188,7 +188,7 @@ def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: Text
                     absorbed_by[j] = i
                     ops.append((1, int(best[i]), int(best[j])))                     # R:248 in-place OR
     if ops:
-        _lib.apply_row_ops(s1, torch.tensor(ops, dtype=torch.int32).to(device))
+        _lib.apply_row_ops(s1, _lib.upload(np.asarray(ops, dtype=np.int32), torch.int32, device))
 
     # R:258-281: stage-2 masks matched to the same stage-1 mask are merged; each current row is
     # tracked as the list of original stage-2 rows it is the OR of
@@ -207,7 +207,7 @@ def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: Text
     if regrouped:
         offs = np.zeros(len(parts) + 1, dtype=np.int32)
         np.cumsum([len(p) for p in parts], out=offs[1:])
-        s2 = _lib.or_reduce_groups(s2, torch.from_numpy(offs).to(device),
+        s2 = _lib.or_reduce_groups(s2, _lib.upload(offs, torch.int32, device),
                                    i32([p for part in parts for p in part]), max(len(p) for p in parts))
 
     if ops or regrouped:            # rows changed: recompute R:285-288; otherwise iou / best are what they were
@@ -220,7 +220,7 @@ def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: Text
     labels = [s1_labels[i] for i in best_l]                                         # R:297
     sims = sim.similarities(text_prompt, labels)                                    # R:299-302
     return _SceneState(scene_id, n, iou[range(len(best)), best], sims,
-                       _lib.gather_rows(s1, best.to(torch.int32).to(device)), s2, conf2,
+                       _lib.gather_rows(s1, _lib.upload(best, torch.int32, device)), s2, conf2,
                        _lib.gather_rows(s1, i32(other)) if other else s1[:0])
 
 
@@ -282,7 +282,7 @@ def _pass2_scene(st: _SceneState, cfg, text_prompt, sim_thres) -> FinalResult:
     if order:
         both = torch.cat([st.matched1, st.stage2_rows])
         k = st.matched1.shape[0]
-        idx = torch.tensor([m if src == 1 else k + m for src, m in order], dtype=torch.int32, device=dev)
+        idx = _lib.upload(np.asarray([m if src == 1 else k + m for src, m in order], dtype=np.int32), torch.int32, dev)
         pieces.append(_lib.gather_rows(both, idx))
     rows = torch.cat(pieces) if len(pieces) > 1 else pieces[0]
     return FinalResult(st.scene_id, st.n_points, rows, torch.stack(conf), cls)       # R:411-412

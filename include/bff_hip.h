@@ -85,6 +85,9 @@ int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const 
  *   frame_flags  int32 [n_frames]: bit0 = add visibility to viewed_count (P:567)
  *   rows         uint64 [n_rows][nw] instance bit rows: zeroed by this call (all n_rows rows), then row
  *                (rowbase+b) receives the points of mask b of every frame with a mask image   (a6, a8)
+ *   chunk_mask   optional uint64 [n_rows][bff_chunk_mask_words(nw)], zeroed by this call: bit c of a row =
+ *                "chunk c (words 8c..8c+7, 512 points) of the row holds a point" -- exactly what bff_row_stats
+ *                computes, for free here; lets bff_row_stats / bff_or_reduce_groups skip the empty 99 %
  *   masked_count int32 [n_points], += number of masks of the frame containing the visible point
  *                (P:459-461 adds 1 per mask, not per view); may be NULL
  *   viewed_count int32 [n_points], += visibility for frames with flag bit0; may be NULL
@@ -103,7 +106,7 @@ int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
                       const void *maskbits, const uint32_t *segmap, int32_t word_bits,
                       const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
                       const int32_t *frame_flags,
-                      uint64_t *rows, int64_t n_rows, int64_t nw,
+                      uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
                       int32_t *masked_count, int32_t *viewed_count, void *stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -127,9 +130,11 @@ int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t na,
  * (512 points), bff_chunk_mask_words(nw) uint64 words per row; hist[r] = uint32 [64] histogram of the
  * row's set bits over 64 equal word ranges (bin width ceil(nw/64) words); signature[r] = int64 key whose bit
  * (62 - b) says "bin b holds >= 15 % of the row" (INT64_MAX for an empty row): rows showing the same object
- * get the same key, so sorting by it clusters them into the same 64-row tiles. */
+ * get the same key, so sorting by it clusters them into the same 64-row tiles.
+ * chunk_mask_given != 0: chunk_mask is an INPUT (as written by bff_project_views) and only the flagged chunks
+ * of every row are read; 0: chunk_mask is computed here from a full pass over the rows. */
 int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *area, int32_t *mean_word,
-                  uint64_t *chunk_mask, uint32_t *hist, int64_t *signature, void *stream);
+                  uint64_t *chunk_mask, int32_t chunk_mask_given, uint32_t *hist, int64_t *signature, void *stream);
 int bff_chunk_mask_words(int64_t nw);
 
 /* a9-a11: merge adjacency of `aggregate` P:100-146.  For every pair (i, j):
@@ -194,14 +199,26 @@ int bff_components_round(const uint64_t *adj, int32_t n_nodes, const int32_t *la
 
 /* a13: out[g] = OR of rows[members[group_offs[g] .. group_offs[g+1])]      (merge_masks P:219-224;
  * also the `.any(dim=0)` merge of R:269).  max_group_size >= the largest group (host knows the groups);
- * it only sizes the launch. */
+ * it only sizes the launch.  conf / conf_mean (optional, both or neither; dtype as bff_group_conf_mean): the
+ * same launch also computes bff_group_conf_mean on extra blocks, so the long sequential sums run beside the OR. */
 int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int32_t *group_offs, const int32_t *members,
-                         int32_t n_groups, int32_t max_group_size, uint64_t *out, void *stream);
+                         int32_t n_groups, int32_t max_group_size, uint64_t *out, const void *conf,
+                         int32_t conf_dtype, void *conf_mean, void *stream);
 
 /* a13: mean[g] = (((c[m0] + c[m1]) + c[m2]) ...) / len, every step rounded to the confidence dtype
  * (P:225: python `sum(conf) / len(conf)` over 0-dim tensors).  dtype: 0 = float32, 1 = float16. */
 int bff_group_conf_mean(const void *conf, int32_t dtype, const int32_t *group_offs, const int32_t *members,
                         int32_t n_groups, void *mean, void *stream);
+
+/* a16 + a14 + the two popcounts around them, fused for k <= bff_resolve_overlaps_max_rows() (64) rows:
+ *   before[i] = inter[i][i]                                   (row popcounts before any edit, P:592)
+ *   solve_overlapping P:285-299 on `rows` in place: pairs (i < j) with inter[i][j] > 0 in the reference's order,
+ *     the row merged from fewer raw masks (size[], ties: row i) loses the points of the other;
+ *   rows[i] &= keep (P:595; keep may be NULL);  after[i] = popcount(rows[i])  (P:596).
+ * inter = bff_cross_popcount(rows, rows) taken BEFORE the call (int32 [k][k]). */
+int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const int32_t *inter, const int32_t *size,
+                         const uint64_t *keep, int32_t *before, int32_t *after, void *stream);
+int bff_resolve_overlaps_max_rows(void);
 
 /* a16/a20: sequential row program applied independently to every word column.
  * ops: int32 [n_ops][3] = (opcode, dst, src) executed in order;

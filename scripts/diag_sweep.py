@@ -22,6 +22,7 @@ _lib.rle_to_maskbits(ds.run_start, ds.run_end, ds.mask_run_offs, ds.view_mask_of
 rows = torch.empty((ds.n_rows, nw), dtype=torch.int64, device=dev)
 masked = torch.zeros(n, dtype=torch.int32, device=dev)
 viewed = torch.zeros(n, dtype=torch.int32, device=dev)
+cm = _lib.chunk_mask_buffer(ds.n_rows, nw, dev)
 def timeit(f, reps=20):
     for _ in range(3): f()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,10 +31,12 @@ def timeit(f, reps=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
 full = lambda: _lib.project_views(ds.xyz, n, ds.inv_pose, ds.cam_intr, ds.depth, ds.depth_index, ds.height, ds.width, DEPTH_THRESH,
-                                  maskbits, ds.word_bits, ds.frame_mask, ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows, masked, viewed, segmap)
+                                  maskbits, ds.word_bits, ds.frame_mask, ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows, masked, viewed, segmap, cm)
 nomask = lambda: _lib.project_views(ds.xyz, n, ds.inv_pose, ds.cam_intr, ds.depth, ds.depth_index, ds.height, ds.width, DEPTH_THRESH,
                                     None, ds.word_bits, ds.frame_mask, ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, None, masked, viewed, None)
 print("sweep full      %.1f us" % timeit(full))
+print("row_stats dense  %.1f us" % timeit(lambda: _lib.row_stats(rows)))
+print("row_stats sparse %.1f us" % timeit(lambda: _lib.row_stats(rows, cm)))
 print("sweep no masks  %.1f us" % timeit(nomask))
 print("decode          %.1f us" % timeit(lambda: _lib.rle_to_maskbits(ds.run_start, ds.run_end, ds.mask_run_offs, ds.view_mask_offs, n_mviews, hw, ds.word_bits, maskbits, segmap)))
 viewed.zero_(); nomask(); torch.cuda.synchronize()

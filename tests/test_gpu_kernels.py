@@ -118,7 +118,14 @@ def run_view(lib, xyz, inv_pose, k33, depth, masks):
     vc = torch.zeros(n, dtype=torch.int32, device=DEV)
     args = (torch.from_numpy(soa).to(DEV), n, torch.from_numpy(inv_pose.reshape(1, 16).copy()).to(DEV), k33,
             torch.from_numpy(depth.reshape(1, -1).copy()).to(DEV), i32([0]), h, w, 0.08)
-    lib.project_views(*args, bits, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows, mc, vc)
+    cm = lib.chunk_mask_buffer(m, nw, DEV)
+    lib.project_views(*args, bits, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows, mc, vc, chunk_mask=cm)
+    # the chunk flags the sweep leaves are exactly the occupancy masks a full pass over the rows computes, and
+    # the statistics read through them equal the dense ones
+    dense_stats = lib.row_stats(rows)
+    assert torch.equal(cm, dense_stats[2])
+    for a, b in zip(lib.row_stats(rows, cm), dense_stats):
+        assert torch.equal(a, b)
     # same sweep over the sparsely written image + segment bitmap
     rows2, mc2, vc2 = torch.empty_like(rows), torch.zeros_like(mc), torch.zeros_like(vc)
     lib.project_views(*args, maskbits_from_dense.last_sparse, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows2, mc2, vc2,
@@ -331,6 +338,9 @@ def test_or_reduce_and_conf_mean(lib, dtype):
     got = lib.group_conf_mean(conf.to(DEV), offs, mem).cpu()
     exp = torch.tensor([sum([conf[i] for i in g]) / len(g) for g in groups])     # P:225, sequential in dtype
     assert got.dtype == dtype and torch.equal(got, exp)
+    # both in one launch (the means on extra blocks beside the OR)
+    out2, got2 = lib.or_reduce_groups(pack_np(d), offs, mem, max(len(g) for g in groups), conf.to(DEV))
+    assert torch.equal(out2, out) and torch.equal(got2.cpu(), exp)
 
 
 def test_row_ops_and_rows(lib):
@@ -365,6 +375,23 @@ def test_resolve_overlaps_golden(lib):
         rows = pack_np(d)
         lib.resolve_overlaps(rows, torch.tensor(sizes, dtype=torch.int32, device=DEV))
         assert np.array_equal(unpack(rows, 3000), exp)
+
+
+@pytest.mark.parametrize("k,n", [(1, 100), (2, 64), (17, 5000), (64, 777), (70, 3000)])
+def test_resolve_overlaps_filtered_equals_separate_steps(lib, k, n):
+    """Fused pass (k <= 64) and the fallback (k = 70) == popcount, resolve_overlaps, and_rows, popcount."""
+    rng = np.random.default_rng(k)
+    d = random_rows(rng, k, n, 0.08)
+    keep = pack_np(rng.random((1, n)) < 0.7)[0]
+    sizes = torch.from_numpy(rng.integers(1, 6, k).astype(np.int32)).to(DEV)        # many ties
+    ref = pack_np(d)
+    before_ref = lib.popcount_rows(ref)
+    lib.resolve_overlaps(ref, sizes)
+    lib.and_rows(ref, keep)
+    after_ref = lib.popcount_rows(ref)
+    rows = pack_np(d)
+    before, after = lib.resolve_overlaps_filtered(rows, sizes, keep)
+    assert torch.equal(rows, ref) and torch.equal(before, before_ref) and torch.equal(after, after_ref)
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 128, 10_001, 16_384 + 64, 200_000])
