@@ -202,7 +202,7 @@ def main():
 
     def _back(i, fr):
         with torch.cuda.stream(streams[i % 2]):
-            res = projection_back(fr)
+            res = projection_back(fr, stage1=stage1)     # the refinement follows: its first device pass rides along
             fin = refine_class([(scene.scene_id, stage1, res)], cfg, QUERY, sim, dev, exchange_sims=exchange)
             rows = fin[scene.scene_id].rows
             if rows is None:

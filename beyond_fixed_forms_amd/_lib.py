@@ -460,33 +460,34 @@ def host_component_csr(comp, has_self_loop, min_members):
     return offs[:k + 1], members[:offs[k]], sizes[:k], int(n_void.value)
 
 
-_up_ring = {}             # (dtype, capacity) -> [buffers, events, next]
+_up_ring = {}             # (dtype, capacity) -> [pinned buffers, their numpy views, events, next]
+_NP_OF = {torch.int32: "int32", torch.int64: "int64", torch.float32: "float32", torch.float16: "float16"}
 
 
 def upload(data, dtype, device):
     """Small host array / list -> device tensor without blocking the host: the values go through a ring of
     pinned staging buffers and an asynchronous copy on the current stream (a pageable `.to(device)` would stall
     the host until everything queued on the stream before it has finished)."""
-    t = data if torch.is_tensor(data) else torch.as_tensor(data)
-    t = t.to(dtype).reshape(-1) if t.dtype != dtype else t.reshape(-1)
-    shape = tuple(data.shape) if hasattr(data, "shape") else (t.numel(),)
-    n = t.numel()
+    import numpy as np
+    a = data.numpy() if torch.is_tensor(data) else np.asarray(data)
+    shape, n = a.shape, a.size
     if torch.device(device).type != "cuda" or n == 0:
-        return t.reshape(shape).to(device)
+        return torch.as_tensor(a).to(dtype).to(device)
     cap = max(64, 1 << (n - 1).bit_length())
     ring = _up_ring.get((dtype, cap))
     if ring is None:
-        ring = _up_ring[(dtype, cap)] = [[torch.empty(cap, dtype=dtype, pin_memory=True) for _ in range(8)],
-                                         [None] * 8, 0]
-    k = ring[2]
-    ring[2] = (k + 1) % 8
-    if ring[1][k] is not None:
-        ring[1][k].synchronize()               # the copy that last used this buffer (8 uploads ago) is long done
-    buf = ring[0][k][:n]
-    buf.copy_(t)
-    out = buf.to(device, non_blocking=True)
-    ev = ring[1][k] = ring[1][k] or torch.cuda.Event()
-    ev.record(torch.cuda.current_stream())
+        bufs = [torch.empty(cap, dtype=dtype, pin_memory=True) for _ in range(8)]
+        ring = _up_ring[(dtype, cap)] = [bufs, [b.numpy() for b in bufs], [None] * 8, 0]
+    k = ring[3]
+    ring[3] = (k + 1) & 7
+    ev = ring[2][k]
+    if ev is not None:
+        ev.synchronize()                       # the copy that last used this buffer (8 uploads ago) is long done
+    else:
+        ev = ring[2][k] = torch.cuda.Event()
+    np.copyto(ring[1][k][:n], a.reshape(-1), casting="same_kind")
+    out = ring[0][k][:n].to(device, non_blocking=True)
+    ev.record()                                # on the current stream
     return out.reshape(shape)
 
 

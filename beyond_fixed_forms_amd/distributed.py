@@ -112,11 +112,11 @@ def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[floa
         with torch.cuda.stream(streams[k % 2]):
             return projection_front(ds, cfg)
 
-    def back(k, fr):
+    def back(k, fr, st1):
         if streams is None:
-            return projection_back(fr)
+            return projection_back(fr, stage1=st1)
         with torch.cuda.stream(streams[k % 2]):
-            res = projection_back(fr)
+            res = projection_back(fr, stage1=st1)
         torch.cuda.current_stream().wait_stream(streams[k % 2])       # results are used on the current stream
         return res
 
@@ -126,7 +126,8 @@ def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[floa
         cur = nxt
         if k + 1 < len(mine):
             nxt = front(k + 1)
-        trip.append((scenes[i].scene_id, prepare_stage1(scenes[i].stage1, device), back(k, cur)))
+        st1 = prepare_stage1(scenes[i].stage1, device)
+        trip.append((scenes[i].scene_id, st1, back(k, cur, st1)))
     exchange = (lambda sims: exchange_similarities(sims, device=device)) if ws > 1 else None
     final = refine_class(trip, cfg, text_prompt, sim, device, exchange_sims=exchange) if trip or ws > 1 else {}
     local = {sid: (r.rows, r.conf, list(r.final_class)) for sid, r in final.items()}

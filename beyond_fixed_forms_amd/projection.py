@@ -34,6 +34,7 @@ class Stage2Result:
     groups: list                  # indices of the raw 2-D masks merged into each *pre-filter* instance
     debug: dict
     conf_host: Optional[torch.Tensor] = None      # `conf` again, on the host (read back with the last fetch)
+    prefetch: Optional[dict] = None               # refinement inputs read back with the same fetch (see projection_back)
 
     @property
     def empty(self):
@@ -227,14 +228,19 @@ def _projection_front(ds, cfg, debug_out, timers) -> _Front:
     return fr
 
 
-def projection_back(fr: _Front, timers=None, phases=None) -> Stage2Result:
+def projection_back(fr: _Front, timers=None, phases=None, stage1=None) -> Stage2Result:
     """Second half: read the components back, group, merge, filter, select (P:203-247, 583-634).  Must run on
-    the stream the front was issued on."""
+    the stream the front was issued on.
+
+    stage1 (optional, a refinement.DeviceStage1 of the same scene): when the refinement of this class follows
+    in the same process, its first device pass (stage-1 decode, areas, stage-1 x stage-2 and stage-1 x stage-1
+    intersections, R:186-217) is issued here and read back with this stage's last fetch, which saves the
+    refinement a synchronisation; `refine_class` picks it up from the result when given the same object."""
     with _lib.launch_stream():
-        return _projection_back(fr, timers, phases)
+        return _projection_back(fr, timers, phases, stage1)
 
 
-def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, phases=None) -> Stage2Result:
+def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, phases=None, stage1=None) -> Stage2Result:
     """P:402-634 for one uploaded scene.  `phases` (dict, diagnostic): wall time per phase with a device
     synchronize at every phase boundary."""
     if phases is not None:
@@ -245,10 +251,10 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, p
         torch.cuda.synchronize()
         phases["front (decode, sweep, threshold, stats, components)"] = \
             phases.get("front (decode, sweep, threshold, stats, components)", 0.0) + time.perf_counter() - t0
-    return projection_back(fr, timers, phases)
+    return projection_back(fr, timers, phases, stage1)
 
 
-def _projection_back(fr: _Front, timers, phases) -> Stage2Result:
+def _projection_back(fr: _Front, timers, phases, stage1=None) -> Stage2Result:
     import time
     _t = [time.perf_counter()]
 
@@ -294,7 +300,10 @@ def _projection_back(fr: _Front, timers, phases) -> Stage2Result:
         return _empty(ds, dbg)
 
     # a13: OR of member rows, sequential mean of confidences, label of the first member (P:214-226)
-    offs_d, members_d = _lib.upload(offs, torch.int32, dev), _lib.upload(members, torch.int32, dev)
+    # one upload for the three group tables (offsets, members, sizes)
+    n_offs, n_mem = offs.shape[0], members.shape[0]
+    packed = _lib.upload(np.concatenate([offs, members, sizes.astype(np.int32, copy=False)]), torch.int32, dev)
+    offs_d, members_d, sizes_d = packed[:n_offs], packed[n_offs:n_offs + n_mem], packed[n_offs + n_mem:]
     agg, conf = _lib.or_reduce_groups(rows, offs_d, members_d, int(sizes.max()), ds.conf)
     first_member = members[offs[:-1]]
     agg_labels = [ds.labels[i] for i in first_member]
@@ -305,7 +314,7 @@ def _projection_back(fr: _Front, timers, phases) -> Stage2Result:
 
     # a16: overlap resolution (P:592-596), decided and applied on the device
     if size_list is None:
-        before, after = _lib.resolve_overlaps_filtered(agg, _lib.upload(sizes, torch.int32, dev), keep)   # P:592-596
+        before, after = _lib.resolve_overlaps_filtered(agg, sizes_d, keep)           # P:592-596
     else:           # sizes indexed like mask_indeces_to_be_merged, which still holds the empty components
         before = _lib.popcount_rows(agg)                                            # P:592
         inter = _lib.cross_popcount(agg, agg).cpu().numpy()
@@ -319,20 +328,35 @@ def _projection_back(fr: _Front, timers, phases) -> Stage2Result:
     mark("overlap")
 
     # a17: size filters with the reference's dtype promotion (int64 vs python scalars, P:601-606)
-    before_h, after_h, conf_h = _lib.fetch(before, after, conf)                     # the second (last) sync
+    agg_u = pre = None
+    if stage1 is not None and stage1.n_points == n:
+        # the refinement's first device pass rides on this fetch: rows in the caller's point order for all K
+        # groups (the selection below only picks among them)
+        agg_u = unsorted(agg)
+        s1 = _lib.rle_to_rows(stage1.run_start, stage1.run_end, stage1.row_run_offs, n)
+        pre_dev = (_lib.popcount_rows(s1), _lib.cross_popcount(s1, agg_u), _lib.cross_popcount(s1, s1))
+        before_h, after_h, conf_h, area1_h, inter_h, inter11_h = _lib.fetch(before, after, conf, *pre_dev)
+    else:
+        before_h, after_h, conf_h = _lib.fetch(before, after, conf)                 # the second (last) sync
     before_t, after_t = torch.from_numpy(before_h).to(torch.int64), torch.from_numpy(after_h).to(torch.int64)
     keep_rows = (after_t > cfg.remove_small_masks) & (after_t > cfg.remove_filtered_masks * before_t)
     idx = torch.nonzero(keep_rows).view(-1).to(torch.int32)
     dbg.update(before=before_t, after=after_t, keep=keep_rows)
     idx_d = _lib.upload(idx, torch.int32, dev)
-    out_rows = unsorted(_lib.gather_rows(agg, idx_d)) if idx.numel() else agg[:0]
+    if agg_u is not None:
+        out_rows = _lib.gather_rows(agg_u, idx_d) if idx.numel() else agg_u[:0]
+        sel = idx.long().numpy()
+        pre = dict(stage1=stage1, s1=s1, area1=area1_h, area2=after_h[sel], inter=np.ascontiguousarray(inter_h[:, sel]),
+                   inter11=inter11_h)
+    else:
+        out_rows = unsorted(_lib.gather_rows(agg, idx_d)) if idx.numel() else agg[:0]
     out_conf = conf[idx_d.long()]
     conf_host = torch.from_numpy(conf_h)[idx.long()]                # the same values, already on the host
     out_labels = [c for c, kk in zip(agg_labels, keep_rows.tolist()) if kk]
     mark("size_filter+output")
     lazy = _LazyGroups(offs, members) if groups is None else groups
     dbg["groups"] = lazy
-    return Stage2Result(ds.scene_id, n, out_rows, out_conf, out_labels, lazy, dbg, conf_host)
+    return Stage2Result(ds.scene_id, n, out_rows, out_conf, out_labels, lazy, dbg, conf_host, pre)
 
 
 def project_scene(scene, cfg, device="cuda", return_result: bool = False, debug_out: bool = False):

@@ -156,7 +156,13 @@ class _SceneState:
 
 
 def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: TextSimilarity, device) -> _SceneState:
-    s1, n, s1_labels = _stage1_rows(stage1, device)
+    pre = stage2.prefetch if isinstance(stage2, Stage2Result) else None
+    if pre is not None and pre["stage1"] is stage1:
+        s1, n, s1_labels = pre["s1"], stage1.n_points, stage1.labels     # decoded by projection_back, still untouched
+        stage2.prefetch = None                                            # pass 1 edits s1 in place: single use
+    else:
+        pre = None
+        s1, n, s1_labels = _stage1_rows(stage1, device)
     s2, conf2 = _stage2_rows(stage2, n, device)
     i32 = lambda lst: _lib.upload(np.asarray(lst, dtype=np.int32), torch.int32, device)
     if len(conf2) == 0:                                                             # R:196-205
@@ -164,10 +170,14 @@ def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: Text
         return _SceneState(scene_id, n, [], [], None, None, [], _lib.gather_rows(s1, i32(other)) if other else s1[:0])
 
     # one read-back for everything pass 1 needs from the device: areas, stage-1 x stage-2 intersections, and
-    # the stage-1 x stage-1 intersections (so the duplicate test R:217 needs no second round trip)
-    area1, area2, inter, inter11 = (torch.from_numpy(a) for a in
-                                    _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2),
-                                               _lib.cross_popcount(s1, s2), _lib.cross_popcount(s1, s1)))
+    # the stage-1 x stage-1 intersections (so the duplicate test R:217 needs no second round trip) -- or none at
+    # all when the projection stage already fetched them (Stage2Result.prefetch)
+    if pre is not None:
+        area1, area2, inter, inter11 = (torch.from_numpy(pre[k]) for k in ("area1", "area2", "inter", "inter11"))
+    else:
+        area1, area2, inter, inter11 = (torch.from_numpy(a) for a in
+                                        _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2),
+                                                   _lib.cross_popcount(s1, s2), _lib.cross_popcount(s1, s1)))
     iou = _iou(inter, area1, area2)                                                 # R:208  (K, S1)
     best = torch.argmax(iou, dim=1)                                                 # R:211
     m_iou = _iou(inter11[best][:, best], area1[best], area1[best])                  # R:217

@@ -149,6 +149,14 @@ def test_scene_vs_oracle(api, case, mode):
     fin = refinement.refine_class([(scene.scene_id, scene.stage1, res)], cfg, "table", sim, DEV)
     fexp = rref.refine_class_ref([(scene.scene_id, scene.stage1, exp)], cfg, "table", enc)
     same(fin[scene.scene_id].to_dict(), fexp[scene.scene_id])
+    # the pipelined form: the refinement's first device pass rides on the projection's last fetch
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    st1 = refinement.prepare_stage1(scene.stage1, DEV)
+    res2 = projection.run_projection(prepare_scene(scene, cfg, device=DEV), cfg, stage1=st1)
+    assert res2.prefetch is not None and torch.equal(res2.rows, res.rows) and torch.equal(res2.conf, res.conf)
+    fin2 = refinement.refine_class([(scene.scene_id, st1, res2)], cfg, "table", sim, DEV)
+    assert res2.prefetch is None                                        # consumed
+    same(fin2[scene.scene_id].to_dict(), fexp[scene.scene_id])
 
 
 @pytest.mark.parametrize("variant", ["dup_stage1_and_shared_match", "nothing_merges", "only_shared_match"])
