@@ -48,7 +48,7 @@ SIGNATURES = {
     "bff_select_unique_rank": [_P, _L, _D, _P, _P, _P, _P],
     "bff_cosine_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
     "bff_sort_f32": [_P, _P, _L, _P, _P, _P],
-    "bff_argsort_i64": [_P, _P, _P, _I, _P, _P, _P],
+    "bff_argsort_i64": [_P, _P, _P, _I, _I, _P, _P, _P],
     "bff_depth_from_u16": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P],
 }
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
@@ -413,14 +413,18 @@ def sort_f32(vals):
     return out
 
 
-def argsort_i64(keys):
-    """Stable ascending argsort of an int64 device vector -> int32 order (bff_argsort_i64)."""
+SIGNATURE_BITS = 30       # bff_row_stats signatures are 30-bit keys
+
+
+def argsort_i64(keys, key_bits=64):
+    """Stable ascending argsort of an int64 device vector -> int32 order (bff_argsort_i64).  key_bits < 64: the
+    keys are known to be non-negative and below 2^key_bits (fewer radix passes)."""
     n = keys.shape[0]
     order = torch.empty(n, dtype=i32, device=keys.device)
     scratch = torch.empty_like(keys)
-    temp, nb = _sort_temp("i64", n, keys.device,
-                          lambda need: call("bff_argsort_i64", None, None, None, n, None, need))
-    call("bff_argsort_i64", _ptr(keys, i64), _ptr(scratch), _ptr(order), n, _ptr(temp), ctypes.byref(nb))
+    temp, nb = _sort_temp(("i64", key_bits), n, keys.device,
+                          lambda need: call("bff_argsort_i64", None, None, None, n, key_bits, None, need))
+    call("bff_argsort_i64", _ptr(keys, i64), _ptr(scratch), _ptr(order), n, key_bits, _ptr(temp), ctypes.byref(nb))
     return order
 
 

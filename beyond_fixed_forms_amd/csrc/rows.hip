@@ -109,6 +109,20 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
 // bits (sort key that brings rows covering the same region of the -- spatially sorted -- cloud together).
 constexpr int kBins = 64;     // histogram bins per row (each ceil(nw/64) words wide)
 
+// 30-bit sort key of a row from its heavy-bin ballot: the first five heavy bins (ascending), 6 bits each, most
+// significant first; unused slots = 63.  Rows of one object share the key whatever the view.
+__device__ __forceinline__ int64_t heavy_signature(uint64_t heavy)
+{
+    uint32_t key = 0;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        int b = 63;
+        if (heavy) { b = __ffsll((unsigned long long)heavy) - 1; heavy &= heavy - 1; }
+        key = (key << 6) | (uint32_t)b;
+    }
+    return (int64_t)key;
+}
+
 __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restrict__ rows, int64_t nw, int mw,
                                                          int bin_words, int32_t *__restrict__ area,
                                                          int32_t *__restrict__ mean_word,
@@ -146,9 +160,9 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restri
     if (tid < kBins) {
         hist[(int64_t)r * kBins + tid] = s_hist[tid];
         // bins holding >= 15 % of the row: rows of one object share this signature whatever the view, and
-        // stray "bleed" points never enter it.  Bin 0 is the most significant bit (sorts like a position).
+        // stray "bleed" points never enter it.
         const uint64_t heavy = __ballot((uint64_t)s_hist[tid] * 100 >= (uint64_t)a_all * 15 && a_all > 0);
-        if (tid == 0) signature[r] = a_all ? (int64_t)(__brevll(heavy) >> 1) : 0x7fffffffffffffffll;
+        if (tid == 0) signature[r] = heavy_signature(a_all ? heavy : 0);
     }
     if (tid == 0) {
         const int a = part[0] + part[1] + part[2] + part[3];
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(256) void row_stats_sparse_kernel(const uint64_t *_
     hist[(int64_t)r * kBins + lane] = hv;
     const uint64_t heavy = __ballot((uint64_t)hv * 100 >= (uint64_t)s * 15 && s > 0);
     if (lane == 0) {
-        signature[r] = s ? (int64_t)(__brevll(heavy) >> 1) : 0x7fffffffffffffffll;
+        signature[r] = heavy_signature(s ? heavy : 0);
         area[r] = s;
         mean_word[r] = s ? (int32_t)(ws / (unsigned long long)s) : 0x7fffffff;
     }

@@ -35,15 +35,16 @@ extern "C" int bff_sort_f32(const float *keys_in, float *keys_out, int64_t n, vo
 }
 
 // order_out = stable ascending argsort of the int64 keys (ties keep their index order; radix sort is stable).
-// keys_scratch: int64 [n] for the sorted keys.  temp == NULL: size query as above.
-extern "C" int bff_argsort_i64(const int64_t *keys, int64_t *keys_scratch, int32_t *order_out, int32_t n, void *temp,
-                               size_t *temp_bytes, void *stream)
+// key_bits = 64: full signed order; key_bits < 64: the keys are non-negative and < 2^key_bits, only those bits
+// are sorted (fewer radix passes).  keys_scratch: int64 [n] for the sorted keys.  temp == NULL: size query.
+extern "C" int bff_argsort_i64(const int64_t *keys, int64_t *keys_scratch, int32_t *order_out, int32_t n,
+                               int32_t key_bits, void *temp, size_t *temp_bytes, void *stream)
 {
-    BFF_REQUIRE(n >= 0 && temp_bytes, "bff_argsort_i64: bad arguments");
+    BFF_REQUIRE(n >= 0 && temp_bytes && key_bits >= 1 && key_bits <= 64, "bff_argsort_i64: bad arguments");
     size_t need = 0;
     const size_t iota_bytes = ((size_t)n * sizeof(int32_t) + 255) & ~(size_t)255;     // identity permutation lives in temp
     hipError_t e = rocprim::radix_sort_pairs(nullptr, need, keys, keys_scratch, (const int32_t *)nullptr, order_out,
-                                             (unsigned)n, 0, 64, as_stream(stream));
+                                             (unsigned)n, 0, (unsigned)key_bits, as_stream(stream));
     if (e != hipSuccess) return fail((int)e, "bff_argsort_i64: %s", hipGetErrorString(e));
     if (!temp) { *temp_bytes = need + iota_bytes; return BFF_OK; }
     BFF_REQUIRE(*temp_bytes >= need + iota_bytes && (n == 0 || (keys && keys_scratch && order_out)),
@@ -52,7 +53,7 @@ extern "C" int bff_argsort_i64(const int64_t *keys, int64_t *keys_scratch, int32
     int32_t *iota = reinterpret_cast<int32_t *>(temp);
     iota_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, as_stream(stream)>>>(iota, n);
     e = rocprim::radix_sort_pairs(reinterpret_cast<char *>(temp) + iota_bytes, need, keys, keys_scratch, iota, order_out,
-                                  (unsigned)n, 0, 64, as_stream(stream));
+                                  (unsigned)n, 0, (unsigned)key_bits, as_stream(stream));
     if (e != hipSuccess) return fail((int)e, "bff_argsort_i64: %s", hipGetErrorString(e));
     return BFF_OK;
 }

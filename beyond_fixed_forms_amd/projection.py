@@ -219,9 +219,9 @@ def _projection_front(ds, cfg, debug_out, timers) -> _Front:
     # in the order (label, heavy-bin signature) so that a tile's rows occupy few chunks.
     with span(timers, "row_stats"):
         area, _mean_word, cmask, hist, sig = _lib.row_stats(rows, cmask_in)
-        order = _lib.argsort_i64(sig)
+        order = _lib.argsort_i64(sig, _lib.SIGNATURE_BITS)
         if ds.n_label_ids > 1:                    # several label strings: cluster by label first (stable on top)
-            order = order[_lib.argsort_i64(ds.label_id[order.long()].to(torch.int64)).long()].contiguous()
+            order = order[_lib.argsort_i64(ds.label_id[order.long()].to(torch.int64), 32).long()].contiguous()
     with span(timers, "merge_components"):
         fr.comp = _lib.merge_components(rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist)
     fr.area = area

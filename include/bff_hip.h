@@ -128,8 +128,9 @@ int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t na,
  * index of its set bits (INT32_MAX for an empty row; a sort key that groups rows covering the same part of
  * the cloud when the points are spatially sorted); chunk_mask[r] = occupancy bits over chunks of 8 words
  * (512 points), bff_chunk_mask_words(nw) uint64 words per row; hist[r] = uint32 [64] histogram of the
- * row's set bits over 64 equal word ranges (bin width ceil(nw/64) words); signature[r] = int64 key whose bit
- * (62 - b) says "bin b holds >= 15 % of the row" (INT64_MAX for an empty row): rows showing the same object
+ * row's set bits over 64 equal word ranges (bin width ceil(nw/64) words); signature[r] = 30-bit key: the indices
+ * of the (at most 6, here: first 5) bins holding >= 15 % of the row, ascending, 6 bits each, most significant
+ * first, unused slots = 63 (an empty row is all 63s and sorts last): rows showing the same object
  * get the same key, so sorting by it clusters them into the same 64-row tiles.
  * chunk_mask_given != 0: chunk_mask is an INPUT (as written by bff_project_views) and only the flagged chunks
  * of every row are read; 0: chunk_mask is computed here from a full pass over the rows. */
@@ -304,10 +305,12 @@ int bff_depth_from_u16(const uint16_t *src, int32_t n_frames, int32_t h_src, int
  * protocol: temp == NULL -> only *temp_bytes is written (no launch); then call again with that much device
  * scratch.  bff_sort_f32: keys_out = keys_in ascending (the input of bff_select_unique_rank).
  * bff_argsort_i64: order_out = stable ascending argsort of int64 keys (ties keep index order), keys_scratch =
- * int64 [n]; used to order the Gram tiles by row signature (and, stably on top, by label id). */
+ * int64 [n]; key_bits = 64 sorts the full signed keys, key_bits < 64 promises 0 <= key < 2^key_bits and sorts
+ * only those bits (fewer radix passes).  Used to order the Gram tiles by row signature (30 bits) and, stably on
+ * top, by label id. */
 int bff_sort_f32(const float *keys_in, float *keys_out, int64_t n, void *temp, size_t *temp_bytes, void *stream);
-int bff_argsort_i64(const int64_t *keys, int64_t *keys_scratch, int32_t *order_out, int32_t n, void *temp,
-                    size_t *temp_bytes, void *stream);
+int bff_argsort_i64(const int64_t *keys, int64_t *keys_scratch, int32_t *order_out, int32_t n, int32_t key_bits,
+                    void *temp, size_t *temp_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a21/a24 -- cosine similarity GEMM on the matrix cores (MFMA f16 -> f32).

@@ -17,4 +17,5 @@ k = torch.randint(0, 1 << 62, (9000,), device=dev, dtype=torch.int64)
 print("sort_f32 200k      %.1f us" % timeit(lambda: _lib.sort_f32(v)))
 print("torch.sort 200k    %.1f us" % timeit(lambda: torch.sort(v)))
 print("argsort_i64 9000   %.1f us" % timeit(lambda: _lib.argsort_i64(k)))
+print("argsort 30 bits    %.1f us" % timeit(lambda: _lib.argsort_i64(k >> 33, 30)))
 print("torch.argsort 9000 %.1f us" % timeit(lambda: torch.argsort(k, stable=True)))

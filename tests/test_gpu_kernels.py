@@ -529,3 +529,6 @@ def test_library_sorts(lib, n):
     keys = torch.randint(-5, 5, (n,), generator=g, dtype=torch.int64) * (1 << 40)
     order = lib.argsort_i64(keys.to(DEV)).cpu().long()
     assert torch.equal(order, torch.argsort(keys, stable=True))     # stable: ties keep index order
+    small = torch.randint(0, 1 << 30, (n,), generator=g, dtype=torch.int64) >> torch.randint(0, 30, (n,), generator=g)
+    order = lib.argsort_i64(small.to(DEV), 30).cpu().long()           # 30-bit keys: fewer radix passes
+    assert torch.equal(order, torch.argsort(small, stable=True))
