@@ -53,7 +53,9 @@ SIGNATURES = {
 }
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
          "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
-         "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P])}
+         "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
+         "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
+         "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}
 ABI_VERSION = 1
 
 
@@ -180,7 +182,7 @@ def cross_popcount(a, b, ia=None, ib=None):
 
 
 def chunk_mask_buffer(n_rows, nw, device):
-    """Uninitialised chunk occupancy masks i64 [n_rows][mw] (bff_project_views zeroes and fills them)."""
+    """Uninitialised chunk occupancy masks i64 [n_rows][mw] (zero them before handing them to project_views)."""
     return torch.empty((n_rows, max(load().bff_chunk_mask_words(nw), 1)), dtype=i64, device=device)
 
 

@@ -12,6 +12,8 @@
 // registers across the frames of the block's frame tile; pose and intrinsics are wave-uniform (scalar loads /
 // kernel arguments).  The frame loop has no block barrier: a wave transposes its ballots through a private LDS
 // slice and stores its own sector of every row of the frame.
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace bff {
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
         }
         if (has_masks) {                                   // wave-uniform
             // the wave's 32-B sector (kPPT words) of each of the frame's nm rows: lane -> (row lane/4 + 16 i,
-            // word lane%4).  Most waves see no mask at all in a given frame: the rows were zeroed by the entry point.
+            // word lane%4).  Most waves see no mask at all in a given frame: the caller zeroed the rows.
             const int64_t rb = frame_rowbase[f];
             const int wd = lane & (kPPT - 1);
             if (__ballot(present != 0)) {
@@ -320,6 +322,37 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
 
 using namespace bff;
 
+// Profiling aid (bench.py): events attached to the next sweep dispatch of this host thread.
+static thread_local hipEvent_t g_sweep_start = nullptr, g_sweep_stop = nullptr;
+
+extern "C" int bff_profile_next_sweep(void *start_event, void *stop_event)
+{
+    g_sweep_start = reinterpret_cast<hipEvent_t>(start_event);
+    g_sweep_stop = reinterpret_cast<hipEvent_t>(stop_event);
+    return BFF_OK;
+}
+
+extern "C" void *bff_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+
+extern "C" int bff_event_destroy(void *event)
+{
+    hipError_t e = hipEventDestroy(reinterpret_cast<hipEvent_t>(event));
+    return e == hipSuccess ? BFF_OK : fail((int)e, "bff_event_destroy: %s", hipGetErrorString(e));
+}
+
+extern "C" int bff_event_elapsed_ms(void *start_event, void *stop_event, float *ms)
+{
+    BFF_REQUIRE(start_event && stop_event && ms, "bff_event_elapsed_ms: null pointer");
+    hipError_t e = hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop_event));
+    if (e == hipSuccess)
+        e = hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start_event), reinterpret_cast<hipEvent_t>(stop_event));
+    return e == hipSuccess ? BFF_OK : fail((int)e, "bff_event_elapsed_ms: %s", hipGetErrorString(e));
+}
+
 extern "C" int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const int32_t *mask_run_offs,
                                    const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels,
                                    int32_t word_bits, void *maskbits, uint32_t *segmap, void *stream)
@@ -364,15 +397,7 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
         BFF_REQUIRE(word_bits == 32 || word_bits == 64, "bff_project_views: word_bits must be 32 or 64");
         BFF_REQUIRE(frame_mask && frame_rowbase && frame_nmask && rows && n_rows >= 0, "bff_project_views: mask frames need row outputs");
     }
-    if (maskbits && n_rows > 0) {       // the kernel stores only the sectors in which a wave saw a mask bit
-        hipError_t e = hipMemsetAsync(rows, 0, sizeof(uint64_t) * (size_t)n_rows * (size_t)nw, as_stream(stream));
-        if (e != hipSuccess) return fail((int)e, "bff_project_views: memset: %s", hipGetErrorString(e));
-    }
     const int mw = (int)ceil_div(ceil_div(nw, kCW), 64);
-    if (maskbits && n_rows > 0 && chunk_mask) {
-        hipError_t e = hipMemsetAsync(chunk_mask, 0, sizeof(uint64_t) * (size_t)n_rows * (size_t)mw, as_stream(stream));
-        if (e != hipSuccess) return fail((int)e, "bff_project_views: memset: %s", hipGetErrorString(e));
-    }
     Intrinsics K;
     for (int i = 0; i < 9; ++i) K.k[i] = cam_intr_host[i];
     const int64_t gx = ceil_div(n_points, kPtsPerBlock);
@@ -380,13 +405,15 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
     fpb = fpb < 1 ? 1 : (fpb > 8 ? 8 : fpb);
     dim3 grid((unsigned)gx, (unsigned)ceil_div(n_frames, fpb));
     const int64_t seg_words = ceil_div(ceil_div((int64_t)height * width, 128), 32);
+    const hipEvent_t ev0 = g_sweep_start, ev1 = g_sweep_stop;   // attached to the dispatch itself when set
+    g_sweep_start = g_sweep_stop = nullptr;
     if (!maskbits || word_bits == 32)
-        project_views_kernel<uint32_t><<<grid, kBlock, 0, as_stream(stream)>>>(
+        hipExtLaunchKernelGGL(project_views_kernel<uint32_t>, grid, dim3(kBlock), 0, as_stream(stream), ev0, ev1, 0,
             xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
             (const uint32_t *)maskbits, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
             chunk_mask, mw, masked_count, viewed_count);
     else
-        project_views_kernel<uint64_t><<<grid, kBlock, 0, as_stream(stream)>>>(
+        hipExtLaunchKernelGGL(project_views_kernel<uint64_t>, grid, dim3(kBlock), 0, as_stream(stream), ev0, ev1, 0,
             xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
             (const uint64_t *)maskbits, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
             chunk_mask, mw, masked_count, viewed_count);

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from .scene import DEPTH_THRESH, DeviceScene, prepare_scene
-from .timing import span
+from .timing import span, sweep_span
 
 
 @dataclasses.dataclass
@@ -193,13 +193,14 @@ def _projection_front(ds, cfg, debug_out, timers) -> _Front:
                              ds.height * ds.width, ds.word_bits, maskbits, segmap)
 
     # a2-a8 (+a15): one fused sweep over the frames (P:413-461 and P:538-567)
-    rows = fr.rows = torch.empty((ds.n_rows, nw), dtype=torch.int64, device=dev)
+    with span(timers, "zero_rows"):       # the sweep stores only the sectors that receive a point
+        rows = fr.rows = torch.zeros((ds.n_rows, nw), dtype=torch.int64, device=dev)
     masked = fr.masked = torch.zeros(n, dtype=torch.int32, device=dev)                          # P:402
     viewed = fr.viewed = torch.zeros(n, dtype=torch.int32, device=dev) if do_ratio else None    # P:537
     n_frames = ds.n_frames if do_ratio else ds.n_mask_frames
     # the sweep flags, per row, the 512-point chunks it stores into: the later passes read nothing else
-    cmask_in = _lib.chunk_mask_buffer(ds.n_rows, nw, dev) if (ds.n_rows and n_mviews) else None
-    with span(timers, "project_views"):
+    cmask_in = _lib.chunk_mask_buffer(ds.n_rows, nw, dev).zero_() if (ds.n_rows and n_mviews) else None
+    with sweep_span(timers, "project_views"):
         _lib.project_views(ds.xyz, n, ds.inv_pose[:n_frames], ds.cam_intr, ds.depth, ds.depth_index, ds.height,
                            ds.width, DEPTH_THRESH, maskbits if n_mviews else None, ds.word_bits, ds.frame_mask,
                            ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows if ds.n_rows else None,

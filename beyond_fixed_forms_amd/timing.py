@@ -20,15 +20,46 @@ class KernelTimers:
         b.record()
         self._events[name].append((a, b))
 
+    @contextlib.contextmanager
+    def sweep_span(self, name):
+        """Span of the projection sweep: the events ride on the kernel dispatch itself (bff_profile_next_sweep),
+        so the elapsed time is the kernel's own duration, not launch + two event packets."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        a, b = lib.bff_event_create(), lib.bff_event_create()
+        if not a or not b:
+            raise RuntimeError("bff_event_create failed")
+        lib.bff_profile_next_sweep(a, b)
+        yield
+        self._events[name].append((ctypes.c_void_p(a), ctypes.c_void_p(b)))
+
     def summary(self):
         """{name: (launches, total_ms, mean_ms)} -- call after a device synchronize."""
+        import ctypes
         out = {}
         for k, evs in self._events.items():
-            ms = [a.elapsed_time(b) for a, b in evs]
+            ms = []
+            for a, b in evs:
+                if isinstance(a, ctypes.c_void_p):
+                    from . import _lib
+                    v = ctypes.c_float(0.0)
+                    if _lib.load().bff_event_elapsed_ms(a, b, ctypes.byref(v)) != 0:
+                        raise RuntimeError(_lib.load().bff_last_error().decode())
+                    ms.append(float(v.value))
+                else:
+                    ms.append(a.elapsed_time(b))
             out[k] = (len(ms), sum(ms), sum(ms) / len(ms))
         return out
 
     def clear(self):
+        import ctypes
+        for evs in self._events.values():
+            for a, b in evs:
+                if isinstance(a, ctypes.c_void_p):
+                    from . import _lib
+                    _lib.load().bff_event_destroy(a)
+                    _lib.load().bff_event_destroy(b)
         self._events.clear()
 
 
@@ -38,4 +69,13 @@ def span(timers, name):
         yield
     else:
         with timers.span(name):
+            yield
+
+
+@contextlib.contextmanager
+def sweep_span(timers, name):
+    if timers is None:
+        yield
+    else:
+        with timers.sweep_span(name):
             yield

@@ -83,9 +83,10 @@ int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const 
  *   frame_rowbase int32 [n_frames]: first instance row of the frame (row = rowbase + bit)
  *   frame_nmask  int32 [n_frames]: number of masks (bits) of the frame, 0..word_bits
  *   frame_flags  int32 [n_frames]: bit0 = add visibility to viewed_count (P:567)
- *   rows         uint64 [n_rows][nw] instance bit rows: zeroed by this call (all n_rows rows), then row
- *                (rowbase+b) receives the points of mask b of every frame with a mask image   (a6, a8)
- *   chunk_mask   optional uint64 [n_rows][bff_chunk_mask_words(nw)], zeroed by this call: bit c of a row =
+ *   rows         uint64 [n_rows][nw] instance bit rows, ZEROED BY THE CALLER (hipMemsetAsync on the same
+ *                stream): row (rowbase+b) receives the points of mask b of every frame with a mask image;
+ *                only 32-byte sectors that hold a point are stored                                (a6, a8)
+ *   chunk_mask   optional uint64 [n_rows][bff_chunk_mask_words(nw)], zeroed by the caller too: bit c of a row =
  *                "chunk c (words 8c..8c+7, 512 points) of the row holds a point" -- exactly what bff_row_stats
  *                computes, for free here; lets bff_row_stats / bff_or_reduce_groups skip the empty 99 %
  *   masked_count int32 [n_points], += number of masks of the frame containing the visible point
@@ -108,6 +109,16 @@ int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
                       const int32_t *frame_flags,
                       uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
                       int32_t *masked_count, int32_t *viewed_count, void *stream);
+
+/* Profiling aid.  bff_profile_next_sweep(start, stop): the next bff_project_views launch of the calling host
+ * thread carries the two events on its dispatch (hipExtLaunchKernelGGL), so that bff_event_elapsed_ms(start,
+ * stop) is the kernel's own duration, as a profiler reports it (events recorded around a launch add the
+ * latency of two barrier packets, ~50 us here).  bff_event_create returns a hipEvent_t (NULL on failure);
+ * bff_event_elapsed_ms waits for `stop`. */
+int bff_profile_next_sweep(void *start_event, void *stop_event);
+void *bff_event_create(void);
+int bff_event_destroy(void *event);
+int bff_event_elapsed_ms(void *start_event, void *stop_event, float *ms);
 
 /* ------------------------------------------------------------------------------------------
  * Bit-row primitives (a8-a13, a16-a20).

@@ -19,10 +19,10 @@ n_mviews = ds.view_mask_offs.shape[0] - 1
 maskbits = torch.empty((n_mviews, hw), device=dev, dtype=torch.int32)
 segmap = torch.empty((n_mviews, _lib.segmap_words(hw)), dtype=torch.int32, device=dev)
 _lib.rle_to_maskbits(ds.run_start, ds.run_end, ds.mask_run_offs, ds.view_mask_offs, n_mviews, hw, ds.word_bits, maskbits, segmap)
-rows = torch.empty((ds.n_rows, nw), dtype=torch.int64, device=dev)
+rows = torch.zeros((ds.n_rows, nw), dtype=torch.int64, device=dev)
 masked = torch.zeros(n, dtype=torch.int32, device=dev)
 viewed = torch.zeros(n, dtype=torch.int32, device=dev)
-cm = _lib.chunk_mask_buffer(ds.n_rows, nw, dev)
+cm = _lib.chunk_mask_buffer(ds.n_rows, nw, dev).zero_()
 def timeit(f, reps=20):
     for _ in range(3): f()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

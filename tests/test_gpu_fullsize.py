@@ -54,7 +54,7 @@ def test_checksums_and_layout_invariance(c2):
     mb = torch.empty((ds_plain.n_mask_frames, ds_plain.height * ds_plain.width), dtype=torch.int32, device=DEV)
     _lib.rle_to_maskbits(ds_plain.run_start, ds_plain.run_end, ds_plain.mask_run_offs, ds_plain.view_mask_offs,
                          ds_plain.n_mask_frames, ds_plain.height * ds_plain.width, 32, mb)
-    rows_a = torch.empty_like(raw)
+    rows_a = torch.zeros_like(raw)
     m_a = torch.zeros(n, dtype=torch.int32, device=DEV)
     v_a = torch.zeros(n, dtype=torch.int32, device=DEV)
     zero_flags = torch.zeros_like(ds_plain.frame_flags)

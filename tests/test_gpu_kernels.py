@@ -113,12 +113,12 @@ def run_view(lib, xyz, inv_pose, k33, depth, masks):
     m = masks.shape[0]
     bits, wb = maskbits_from_dense(lib, [masks.reshape(m, -1).astype(bool)], h * w)
     i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)
-    rows = torch.empty((m, nw), dtype=torch.int64, device=DEV)
+    rows = torch.zeros((m, nw), dtype=torch.int64, device=DEV)       # the sweep stores only sectors with a point
     mc = torch.zeros(n, dtype=torch.int32, device=DEV)
     vc = torch.zeros(n, dtype=torch.int32, device=DEV)
     args = (torch.from_numpy(soa).to(DEV), n, torch.from_numpy(inv_pose.reshape(1, 16).copy()).to(DEV), k33,
             torch.from_numpy(depth.reshape(1, -1).copy()).to(DEV), i32([0]), h, w, 0.08)
-    cm = lib.chunk_mask_buffer(m, nw, DEV)
+    cm = lib.chunk_mask_buffer(m, nw, DEV).zero_()
     lib.project_views(*args, bits, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows, mc, vc, chunk_mask=cm)
     # the chunk flags the sweep leaves are exactly the occupancy masks a full pass over the rows computes, and
     # the statistics read through them equal the dense ones
@@ -127,7 +127,7 @@ def run_view(lib, xyz, inv_pose, k33, depth, masks):
     for a, b in zip(lib.row_stats(rows, cm), dense_stats):
         assert torch.equal(a, b)
     # same sweep over the sparsely written image + segment bitmap
-    rows2, mc2, vc2 = torch.empty_like(rows), torch.zeros_like(mc), torch.zeros_like(vc)
+    rows2, mc2, vc2 = torch.zeros_like(rows), torch.zeros_like(mc), torch.zeros_like(vc)
     lib.project_views(*args, maskbits_from_dense.last_sparse, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows2, mc2, vc2,
                       segmap=maskbits_from_dense.last_segmap)
     assert torch.equal(rows2, rows) and torch.equal(mc2, mc) and torch.equal(vc2, vc)
