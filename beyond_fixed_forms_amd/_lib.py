@@ -243,10 +243,11 @@ def merge_adjacency(rows, area, label_id, iou_thres, order=None, chunk_mask=None
     return (adj, inter) if want_inter else adj
 
 
-def permute_bits(rows, idx, n_out):
-    """out[r] bit o = rows[r] bit idx[o]."""
+def permute_bits(rows, idx, n_out, out=None):
+    """out[r] bit o = rows[r] bit idx[o].  out: optional destination (contiguous int64 [rows][ceil(n_out/64)])."""
     nw_out = (n_out + 63) // 64
-    out = torch.empty((rows.shape[0], nw_out), dtype=i64, device=rows.device)
+    if out is None:
+        out = torch.empty((rows.shape[0], nw_out), dtype=i64, device=rows.device)
     call("bff_permute_bits", _ptr(rows, i64), rows.shape[0], rows.shape[1], _ptr(idx, i32), n_out, nw_out, _ptr(out))
     return out
 
@@ -355,10 +356,10 @@ def pack_rows(dense):
     return rows
 
 
-def rle_to_rows(run_start, run_end, row_run_offs, n_points):
+def rle_to_rows(run_start, run_end, row_run_offs, n_points, out=None):
     k = row_run_offs.shape[0] - 1
     nw = (n_points + 63) // 64
-    rows = torch.empty((k, nw), dtype=i64, device=run_start.device)
+    rows = out if out is not None else torch.empty((k, nw), dtype=i64, device=run_start.device)
     call("bff_rle_to_rows", _ptr(run_start, i32), _ptr(run_end, i32), _ptr(row_run_offs, i32), k, n_points, nw, _ptr(rows))
     return rows
 

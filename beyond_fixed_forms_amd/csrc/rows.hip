@@ -502,12 +502,17 @@ __global__ __launch_bounds__(256) void uf_skeleton_kernel(const uint64_t *__rest
     (void)n_strides;
     if (p + stride >= n) return;
     const int i = order ? order[p] : p, j = order ? order[p + stride] : p + stride;
-    if (label_id[i] != label_id[j]) return;
+    // everything the wave needs about the two rows is requested at once (one memory round trip): labels, areas
+    // and the occupancy words (lane m holds word m of both rows; mw <= 64 = kMaxChunks / 64)
+    const int li = label_id[i], lj = label_id[j];
+    const int ai = area[i], aj = area[j];
+    const uint64_t shared_chunks = lane < mw ? (cmask[(int64_t)i * mw + lane] & cmask[(int64_t)j * mw + lane]) : 0;
+    if (li != lj) return;
     const uint64_t *ri = rows + (int64_t)i * nw, *rj = rows + (int64_t)j * nw;
     int acc = 0;
     const int sub = lane >> 3, cw = lane & 7;                        // 8 chunks x 8 words per step
     for (int m = 0; m < mw; ++m) {                                   // wave-uniform walk over shared chunks
-        uint64_t bits = cmask[(int64_t)i * mw + m] & cmask[(int64_t)j * mw + m];
+        uint64_t bits = __shfl(shared_chunks, m);
         while (bits) {
             int mine = -1;                                           // the sub-th set bit of this batch, if any
 #pragma unroll
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(256) void uf_skeleton_kernel(const uint64_t *__rest
     for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
     if (lane == 0) {
         const float fi = (float)acc;
-        const float iou = __fdiv_rn(fi, (float)area[i] + (float)area[j] - fi);
+        const float iou = __fdiv_rn(fi, (float)ai + (float)aj - fi);
         if (iou > thr) uf_union(parent, i, j);
     }
 }

@@ -332,11 +332,20 @@ def _projection_back(fr: _Front, timers, phases, stage1=None) -> Stage2Result:
     agg_u = pre = None
     if stage1 is not None and stage1.n_points == n:
         # the refinement's first device pass rides on this fetch: rows in the caller's point order for all K
-        # groups (the selection below only picks among them)
-        agg_u = unsorted(agg)
-        s1 = _lib.rle_to_rows(stage1.run_start, stage1.run_end, stage1.row_run_offs, n)
-        pre_dev = (_lib.popcount_rows(s1), _lib.cross_popcount(s1, agg_u), _lib.cross_popcount(s1, s1))
-        before_h, after_h, conf_h, area1_h, inter_h, inter11_h = _lib.fetch(before, after, conf, *pre_dev)
+        # groups (the selection below only picks among them);
+        # one buffer [K groups | S1 stage-1 rows] so that one intersection launch serves both products
+        k_all, s1_n = agg.shape[0], stage1.row_run_offs.shape[0] - 1
+        both = torch.empty((k_all + s1_n, ds.nw), dtype=torch.int64, device=dev)
+        agg_u, s1 = both[:k_all], both[k_all:]
+        if ds.unsort is not None:
+            _lib.permute_bits(agg, ds.unsort, n, out=agg_u)
+        else:
+            agg_u.copy_(agg)
+        _lib.rle_to_rows(stage1.run_start, stage1.run_end, stage1.row_run_offs, n, out=s1)
+        cross = _lib.cross_popcount(s1, both)                        # [S1][K + S1]
+        before_h, after_h, conf_h, cross_h = _lib.fetch(before, after, conf, cross)
+        inter_h, inter11_h = cross_h[:, :k_all], cross_h[:, k_all:]
+        area1_h = np.ascontiguousarray(np.diagonal(inter11_h))       # |row & row| = its area
     else:
         before_h, after_h, conf_h = _lib.fetch(before, after, conf)                 # the second (last) sync
     before_t, after_t = torch.from_numpy(before_h).to(torch.int64), torch.from_numpy(after_h).to(torch.int64)
