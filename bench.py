@@ -179,7 +179,7 @@ def main():
     enc = bank_encoder(bank.float(), index)
     sim = TextSimilarity(enc, dev)
     t_setup = time.perf_counter() - t0
-    exchange = (lambda sims: bdist.exchange_similarities(sims, device=dev)) if world > 1 else None
+    exchange = bdist.ClassExchange("cpu" if rehearse else dev) if world > 1 else None     # sims + result-size bounds, one all-gather
     if world > 1:
         dist.barrier()
 
@@ -209,7 +209,7 @@ def main():
             rows = fin[scene.scene_id].rows
             if rows is None:
                 rows = torch.zeros((0, ds.nw), dtype=torch.int64, device=dev)
-            gathered = bdist.gather_final_rows(rows)
+            gathered = bdist.gather_final_rows(rows, bounds=exchange.bounds if exchange is not None else None)
         return res, fin, gathered
 
     def run_steps(k, tm=None):

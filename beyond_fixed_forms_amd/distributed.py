@@ -62,13 +62,61 @@ def exchange_similarities(local_sims: List[List[float]], device="cpu") -> List[L
     return [o[1:1 + int(o[0].item())].tolist() for o in out]
 
 
-def gather_final_rows(rows: torch.Tensor, dst: int = 0):
+class ClassExchange:
+    """The one exchange of a class as a callable for `refine_class(exchange_sims=...)`: a single all-gather
+    carries every rank's similarity set AND its bound on the final rows it will produce (known after pass 1:
+    matched stage-2 rows + other stage-1 masks of the query label, R:293, 340-392), so that the later gather of
+    the results (`gather_final_rows(rows, bounds=exchange.bounds)`) needs no size exchange and no host
+    synchronisation of its own."""
+    takes_bounds = True
+
+    def __init__(self, device="cpu"):
+        self.device = device
+        self.bounds = None                      # (max rows, max words) over all ranks after a call
+
+    def __call__(self, local_sims, bounds=(0, 1)):
+        rank, ws = world()
+        if ws == 1:
+            self.bounds = (int(bounds[0]), int(bounds[1]))
+            return local_sims
+        uniq = sorted(set(s for sims in local_sims for s in sims))
+        if len(uniq) > MAX_SIMS:
+            raise ValueError(f"{len(uniq)} distinct similarities on one rank (> {MAX_SIMS})")
+        host = torch.zeros(MAX_SIMS + 3, dtype=torch.float64)
+        host[0], host[1], host[2] = len(uniq), float(bounds[0]), float(bounds[1])
+        if uniq:
+            host[3:3 + len(uniq)] = torch.tensor(uniq, dtype=torch.float64)
+        buf = host if dist.get_backend() != "nccl" else host.to(self.device)
+        out = [torch.empty_like(buf) for _ in range(ws)]
+        dist.all_gather(out, buf)
+        out = [o.cpu() for o in out]
+        self.bounds = (max(int(o[1]) for o in out), max(1, max(int(o[2]) for o in out)))
+        return [o[3:3 + int(o[0])].tolist() for o in out]
+
+
+def gather_final_rows(rows: torch.Tensor, dst: int = 0, bounds=None):
     """Gather every rank's final bit rows (int64 [R][nw], R and nw may differ per rank) on `dst`.
-    Returns, on dst, a list with one int64 [R_r][nw_r] tensor per rank; elsewhere None."""
+    Returns, on dst, a list with one int64 [R_r][nw_r] tensor per rank; elsewhere None.
+
+    bounds = (max rows, max words) agreed beforehand (ClassExchange.bounds): ONE collective and no host
+    synchronisation -- every rank sends a [1 + max rows][max words] buffer whose first row holds its real
+    (R, nw); dst gets the padded buffers back as `PaddedRows` (decoded on demand)."""
     rank, ws = world()
     if ws == 1:
         return [rows]
     dev = rows.device
+    if bounds is not None:
+        r_max, w_max = int(bounds[0]), max(2, int(bounds[1]))
+        if rows.shape[0] > r_max or rows.shape[1] > w_max:
+            raise ValueError(f"rows {tuple(rows.shape)} exceed the agreed bounds {(r_max, w_max)}")
+        pad = torch.zeros((r_max + 1, w_max), dtype=torch.int64, device=dev)
+        pad[0, 0], pad[0, 1] = rows.shape[0], rows.shape[1]
+        if rows.numel():
+            pad[1:1 + rows.shape[0], :rows.shape[1]] = rows
+        pad = _coll_device(pad)
+        bufs = [torch.empty_like(pad) for _ in range(ws)] if rank == dst else None
+        dist.gather(pad, bufs, dst=dst)
+        return None if rank != dst else [PaddedRows(b, dev) for b in bufs]
     shape = _coll_device(torch.tensor([rows.shape[0], rows.shape[1]], dtype=torch.int64, device=dev))
     shapes = [torch.empty_like(shape) for _ in range(ws)]
     dist.all_gather(shapes, shape)
@@ -83,6 +131,21 @@ def gather_final_rows(rows: torch.Tensor, dst: int = 0):
     if rank != dst:
         return None
     return [b[:int(s[0]), :int(s[1])].to(dev) for b, s in zip(bufs, shapes)]
+
+
+class PaddedRows:
+    """One rank's gathered buffer: row 0 = (R, nw), rows 1..R the bit rows.  `.rows()` decodes (reads the header
+    on the host, i.e. waits for the gather)."""
+
+    def __init__(self, buf, device):
+        self.buf, self.device = buf, device
+
+    def rows(self):
+        r, w = (int(v) for v in self.buf[0, :2].cpu())
+        return self.buf[1:1 + r, :w].to(self.device)
+
+    def tolist(self):
+        return self.rows().tolist()
 
 
 def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[float] = None):

@@ -321,7 +321,13 @@ def _refine_class(scenes, cfg, text_prompt, sim, device, exchange_sims, return_d
             continue
         states.append(_pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim, device))
     all_sims = [st.sims for st in states]
-    pool = exchange_sims(all_sims) if exchange_sims is not None else all_sims
+    if exchange_sims is not None and getattr(exchange_sims, "takes_bounds", False):
+        # what this rank can at most deliver: matched stage-2 rows + other stage-1 masks, widest row
+        bound_rows = sum(len(st.ious) + st.other1.shape[0] for st in states)
+        bound_words = max([st.other1.shape[1] for st in states] + [1])
+        pool = exchange_sims(all_sims, bounds=(bound_rows, bound_words))
+    else:
+        pool = exchange_sims(all_sims) if exchange_sims is not None else all_sims
     thres = sim_threshold(pool, cfg.refinment_sim_percentile)                       # R:321-324
     out = {}
     for s, (scene_id, _s1, _s2) in enumerate(scenes):                               # R:330 (index s, as the reference)

@@ -30,6 +30,14 @@ def _worker(rank, world, port, q):
     thr = sim_threshold(pooled, 0.2)
     rows = torch.full((rank + 1, 3 + rank), rank + 7, dtype=torch.int64)                 # ragged shapes per rank
     gathered = bd.gather_final_rows(rows)
+    # the same with the sizes agreed in the similarity exchange: one all-gather + one gather, no size exchange
+    ex = bd.ClassExchange()
+    pooled2 = ex(local, bounds=(rows.shape[0], rows.shape[1]))
+    assert sorted(map(sorted, pooled2)) == sorted(map(sorted, pooled)) and ex.bounds == (2, 4)
+    g2 = bd.gather_final_rows(rows, bounds=ex.bounds)
+    assert (g2 is None) == (gathered is None)
+    if g2 is not None:
+        assert [g.tolist() for g in g2] == [g.tolist() for g in gathered]
     q.put((rank, mine, thr, None if gathered is None else [g.tolist() for g in gathered]))
     dist.barrier()
     dist.destroy_process_group()
