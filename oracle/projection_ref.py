@@ -189,10 +189,21 @@ def empty_result():
     return {"ins": torch.tensor([[]]), "conf": torch.tensor([]), "final_class": []}
 
 
-def project_scene_ref(scene, cfg, return_debug: bool = False):
+def project_scene_ref(scene, cfg, return_debug: bool = False, stage_times: dict = None):
     """One iteration of the scene loop, reference :365-634, on in-memory inputs.
 
-    Returns the dict the reference saves to mask_3d_dir/<cls>/<scene>.pth."""
+    Returns the dict the reference saves to mask_3d_dir/<cls>/<scene>.pth.  stage_times (optional dict):
+    receives the wall time of the stages SURVEY.md 8(d) lists -- (i) projection+votes, (ii) Gram+merge,
+    (iii) ratio-filter sweep, (iv) overlap+filters."""
+    import time
+    _t = [time.perf_counter()]
+
+    def lap(name):
+        if stage_times is not None:
+            now = time.perf_counter()
+            stage_times[name] = stage_times.get(name, 0.0) + now - _t[0]
+            _t[0] = now
+
     dbg = {}
     cam_intr = np.asarray(scene.cam_intr)[:3, :3]                               # :376
     cloud_h = homogeneous_cloud(np.asarray(scene.points))                      # :387-390
@@ -216,6 +227,7 @@ def project_scene_ref(scene, cfg, return_debug: bool = False):
         for row in mp:                                                         # :459-461
             masked_counts[row] += 1
     dbg["masked_counts_raw"] = masked_counts.clone()
+    lap("i_projection_votes")
     if len(raw["conf"]) == 0:                                                  # :465-478
         return (empty_result(), dbg) if return_debug else empty_result()
     raw["ins"] = torch.stack(raw["ins"], dim=0)                                # :481
@@ -223,6 +235,7 @@ def project_scene_ref(scene, cfg, return_debug: bool = False):
     dbg["raw_ins"] = raw["ins"]
     agg, groups = aggregate(raw, cfg.iou_thres, cfg.min_aggragated_masks)      # :489
     dbg["groups"] = groups
+    lap("ii_gram_merge")
     if len(agg["conf"]) == 0:                                                  # :496-509
         return (empty_result(), dbg) if return_debug else empty_result()
 
@@ -246,6 +259,7 @@ def project_scene_ref(scene, cfg, return_debug: bool = False):
         dbg["thr"] = float(thr)
     keep_pts = masked_counts > 0                                               # :583
     dbg["keep_pts"] = keep_pts
+    lap("iii_ratio_filter_sweep")
 
     before = agg["ins"].sum(dim=1)                                             # :592
     agg["ins"] = resolve_overlaps(agg["ins"], groups)                          # :594
@@ -258,4 +272,5 @@ def project_scene_ref(scene, cfg, return_debug: bool = False):
         "conf": agg["conf"][keep],                                             # :610-616
         "final_class": [c for c, k in zip(agg["final_class"], keep.tolist()) if k],  # :617-623
     }
+    lap("iv_overlap_filters")
     return (out, dbg) if return_debug else out
