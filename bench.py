@@ -292,7 +292,9 @@ def main():
                        "pipelining": "none" if args.no_pipeline else
                        "2 HIP streams: front half of scene i+1 overlaps the host-side back half of scene i"},
             "roofline": {"bound": "hbm", "kernel": "project_views_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic["bytes"] if traffic else None,      # HBM bytes per launch from the PMC counters
+                         "traffic_detail": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": pv[2], "launches": pv[0],
                          "with_row_zero_fill": with_fill(pv[2], zr[2]) if zr else None,
                          "alone_on_chip": (lambda sq: {"avg_launch_ms": sq["project_views"][2],
