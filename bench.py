@@ -64,37 +64,102 @@ def bank_encoder(bank, index):
     return enc
 
 
-def cpu_baseline(scene, cfg, enc, n_sample_views=100):
+def cpu_baseline(scene, cfg, enc, n_sample_views=100, threads=16):
     """Oracle (CPU restatement of the reference) on a bounded sample (~10-30 s of CPU work): the first
     `n_sample_views` frames of the same scene at full N / HxW / M, whole path (projection, aggregation of
     the sample's instances, ratio sweep, filters, refinement); the projection time is scaled linearly to the
     scene's views, which favours the CPU (its aggregation grows quadratically with the instance count)."""
     from oracle.projection_ref import project_scene_ref
     from oracle.refinement_ref import refine_class_ref
-    torch.set_num_threads(16)
+    torch.set_num_threads(threads)
     sub = copy.copy(scene)
     sub.mask_2d = [dict(f) for f in scene.mask_2d[:n_sample_views]]
     ratio = cfg.downsample_ratio
     keep = {f["frame_id"] for f in sub.mask_2d}
     sub.color_files = [f for f in scene.color_files if int(f[:-4]) < n_sample_views * ratio]
+    stages = {}
     t0 = time.perf_counter()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        res = project_scene_ref(sub, cfg)
+        res = project_scene_ref(sub, cfg, stage_times=stages)
         t1 = time.perf_counter()
         try:
             refine_class_ref([(sub.scene_id, sub.stage1, res)], cfg, QUERY, enc)
         except IndexError:
             pass
     t2 = time.perf_counter()
+    stages["v_refinement"] = t2 - t1
     n_views = len(scene.mask_2d)
     est_scene_s = (t1 - t0) * n_views / max(1, len(sub.mask_2d)) + (t2 - t1)
-    return {"value": 1.0 / est_scene_s, "unit": "scenes/s", "cores": 16, "kind": "port",
+    return {"stages_sample_s": {k: round(v, 4) for k, v in stages.items()},     # SURVEY 8(d) stages (i)-(v), on the sample
+            "value": 1.0 / est_scene_s, "unit": "scenes/s", "cores": 16, "kind": "port",
             "sample": f"oracle projection+refinement on {len(sub.mask_2d)} of {n_views} mask views and "
                       f"{(len(sub.color_files) + ratio - 1) // ratio} viewed frames at full N/HxW/M ({t2 - t0:.1f} s CPU), "
                       f"projection scaled linearly to {n_views} views; the reference's O(Ins^2) label loop and "
                       f"O(Ins^4) closure are NOT included (oracle uses integer ids and a frontier search)",
             "sample_seconds": t2 - t0}
+
+
+def cpu_stagewise(args):
+    """`--cpu-stagewise`: stage-wise CPU timings of the reference path beside the GPU path on this
+    machine's host cores -- part of the cpu_baseline leg.  The oracle gives stages (i) projection+votes, (ii)
+    Gram+merge as the oracle does it (integer label ids, frontier search), (iii) ratio-filter sweep, (iv)
+    overlap+filters, (v) refinement on a sample of the views, scaled as noted.  The reference's own formulation of
+    (ii) -- a Python double loop over label strings (P:169-187) and the transitive closure by Ins rounds of
+    clamp(R@A + A) (P:250-274) -- is restated here, timed at small instance counts and extrapolated (O(Ins^2),
+    O(Ins^4)), clearly labelled as such."""
+    import functools
+    say = functools.partial(print, flush=True)
+    threads = int(os.environ.get("BFF_CPU_THREADS", "16"))      # the GPU box gives one GPU's share of the host
+    torch.set_num_threads(threads)
+    say(f"host: {os.cpu_count()} logical cores; torch threads {threads}; model:",
+        next((ln.split(":")[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "?"))
+    n_sample = args.cpu_sample_views
+    scene = make_scene(args.shape, seed=0, query=QUERY, device="cuda" if torch.cuda.is_available() else "cpu")
+    cfg = Config.with_defaults(width_2d=scene.width, height_2d=scene.height)
+    bank, index = make_text_bank(768, seed=0)
+    base = cpu_baseline(scene, cfg, bank_encoder(bank.float(), index), n_sample_views=n_sample, threads=threads)
+    st = base["stages_sample_s"]
+    n_views = len(scene.mask_2d)
+    n_used = min(n_sample, n_views)
+    ins_full = sum(len(f["segmented_frame_masks"]) for f in scene.mask_2d)
+    scale = n_views / max(1, n_used)
+    say(f"\n{args.shape}: oracle on {n_used} of {n_views} mask views, Ins = {ins_full} in the whole scene, N = {scene.points.shape[0]}")
+    say(f"{'stage':34s} {'sample s':>10s} {'scaled to the scene s':>24s}")
+    rows = [("i_projection_votes", scale, "linear in views"), ("ii_gram_merge", scale ** 2, "oracle formulation, ~Ins^2"),
+            ("iii_ratio_filter_sweep", scale, "linear in frames"), ("iv_overlap_filters", 1.0, "K^2 N, K small"),
+            ("v_refinement", 1.0, "S1 K N")]
+    tot = 0.0
+    for k, f, note in rows:
+        v = st.get(k, 0.0)
+        tot += v * f
+        say(f"{k:34s} {v:10.3f} {v * f:24.3f}   ({note})")
+    say(f"{'sum (oracle formulation)':34s} {sum(st.values()):10.3f} {tot:24.3f}")
+
+    def label_loop(labels):                       # P:169-187: Python double loop over strings
+        n = len(labels)
+        m = torch.zeros((n, n))
+        for i in range(n):
+            for j in range(n):
+                if labels[i] == labels[j]:
+                    m[i, j] = 1
+        return m
+
+    def closure(adj):                             # P:250-274: n rounds of clamp(R @ A + A, 0, 1)
+        r = adj.clone()
+        for _ in range(adj.shape[0]):
+            r = torch.clamp(r @ adj + adj, 0, 1)
+        return r
+
+    say("\nreference formulation of stage (ii), measured small and extrapolated to Ins =", ins_full)
+    g = torch.Generator().manual_seed(0)
+    for n in (256, 512, 1024):
+        t0 = time.perf_counter(); label_loop(["table"] * n); t1 = time.perf_counter()
+        a = (torch.rand((n, n), generator=g) < 4.0 / n).float()
+        a = ((a + a.T) > 0).float()
+        t2 = time.perf_counter(); closure(a); t3 = time.perf_counter()
+        say(f"  Ins={n:5d}: label loop {t1 - t0:8.3f} s -> x(Ins/n)^2 = {(t1 - t0) * (ins_full / n) ** 2:12.1f} s;   "
+            f"closure {t3 - t2:8.3f} s -> x(Ins/n)^4 = {(t3 - t2) * (ins_full / n) ** 4:14.1f} s")
 
 
 MFMA_F16_PEAK_TFLOPS = 2500.0     # dense f16/bf16 MFMA peak of MI355X (MI355X_MICROARCH.md; not the 2:1 sparse figure)
@@ -143,12 +208,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", default="c2", choices=list(SHAPES) + ["c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-stagewise", action="store_true",
+                    help="print the stage-wise CPU (oracle) timings of SURVEY 8(d) for --shape and exit")
+    ap.add_argument("--cpu-sample-views", type=int, default=100)
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish every scene before starting the next (default: the GPU-only front half of the next "
                          "scene is issued on a second HIP stream while the host finishes the current one)")
     args = ap.parse_args()
     if args.shape == "c5":
         return bench_cosine(args)
+    if args.cpu_stagewise:
+        return cpu_stagewise(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -9,7 +9,7 @@ from beyond_fixed_forms_amd.projection import projection_back, projection_front
 from beyond_fixed_forms_amd.refinement import TextSimilarity, prepare_stage1, refine_class
 from beyond_fixed_forms_amd.scene import prepare_scene
 from beyond_fixed_forms_amd.synthetic import make_scene, make_text_bank
-from oracle.make_golden_shared import bank_encoder
+import bench
 _lib.load()
 dev = "cuda:0"
 shape = sys.argv[1] if len(sys.argv) > 1 else "c2"
@@ -19,7 +19,7 @@ cfg = Config.with_defaults(width_2d=scene.width, height_2d=scene.height)
 ds = prepare_scene(scene, cfg, device=dev)
 stage1 = prepare_stage1(scene.stage1, dev)
 bank, index = make_text_bank(768, seed=0)
-sim = TextSimilarity(bank_encoder(bank.float(), index), dev)
+sim = TextSimilarity(bench.bank_encoder(bank.float(), index), dev)
 streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
 def front(i):
     with torch.cuda.stream(streams[i % 2]):
