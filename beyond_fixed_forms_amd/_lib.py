@@ -214,7 +214,7 @@ def merge_components(rows, area, label_id, iou_thres, order, chunk_mask, hist, d
     if init:
         parent = torch.empty(n, dtype=i32, device=rows.device)
     comp = torch.empty(n, dtype=i32, device=rows.device)
-    hist_sorted = torch.empty(64 * 64 * nt + 65 * nt, dtype=i32, device=rows.device)      # scratch, see bff_hip.h
+    hist_sorted = torch.empty(64 * 64 * nt + 65 * nt + 1 + nt * (nt + 1) // 2, dtype=i32, device=rows.device)  # scratch, see bff_hip.h
 
     def run(ordr, init_parent, out):
         call("bff_merge_components", _ptr(rows, i64), n, rows.shape[1], _ptr(ordr, i32), ordr.shape[0],

@@ -540,46 +540,79 @@ __global__ __launch_bounds__(256) void uf_skeleton_kernel(const uint64_t *__rest
 
 // Tile pairs are enumerated diagonal-first (|bi - bj| = 0, 1, 2, ...): with rows clustered by signature
 // the first tiles discover the large components, and later tiles find most of their possible edges
-// already inside one component and skip their word loop.
-__global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
-                                                                const int32_t *__restrict__ order,
-                                                                const uint64_t *__restrict__ tmask, int mw,
-                                                                const uint32_t *__restrict__ hist, int n_pos,
-                                                                const int32_t *__restrict__ area,
-                                                                const int32_t *__restrict__ label_id, float thr,
-                                                                int32_t *__restrict__ parent, int n_tiles,
-                                                                const uint32_t *__restrict__ tile_hmax,
-                                                                const int32_t *__restrict__ tile_amin,
-                                                                int32_t *__restrict__ diag)
+// already inside one component and skip their word loop.  index t -> (bi, d = bj - bi).
+__device__ __forceinline__ void tile_pair_of(int t, int n_tiles, int &bi, int &d)
+{
+    // offset of diagonal d: d * n_tiles - d (d - 1) / 2; invert with a float estimate and fix up
+    const double a = 2.0 * n_tiles + 1.0;
+    int dd = (int)((a - sqrt(a * a - 8.0 * (double)t)) * 0.5);
+    dd = max(0, min(dd, n_tiles - 1));
+    auto off = [&](int q) { return (int64_t)q * n_tiles - (int64_t)q * (q - 1) / 2; };
+    while (dd > 0 && off(dd) > t) --dd;
+    while (dd + 1 < n_tiles && off(dd + 1) <= t) ++dd;
+    d = dd;
+    bi = (int)(t - off(dd));
+}
+
+// Tile-level quick reject for every tile pair, ahead of the tile pass: the pairs that can hold an edge are
+// appended to `list` (wave-aggregated, so the list keeps the diagonal-first order up to wave granularity).
+// Every pair of rows of tiles (A, B) has I <= u = sum_b min(maxA[b], maxB[b]) and a_i + a_j >= aminA + aminB,
+// hence IoU = I / (a_i + a_j - I) <= u / (aminA + aminB - u) whenever that denominator is positive (float32
+// evaluation is monotone in both arguments); otherwise no conclusion.
+__global__ __launch_bounds__(256) void tile_pair_filter_kernel(const uint32_t *__restrict__ tile_hmax,
+                                                                const int32_t *__restrict__ tile_amin, int n_tiles,
+                                                                int total, float thr, int32_t *__restrict__ list,
+                                                                int32_t *__restrict__ count)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    bool possible = false;
+    if (t < total) {
+        int bi, d;
+        tile_pair_of(t, n_tiles, bi, d);
+        const int bj = bi + d;
+        const int amin_a = tile_amin[bi], amin_b = tile_amin[bj];
+        if (amin_a != 0x7fffffff && amin_b != 0x7fffffff) {         // a tile of empty rows has no edges at all
+            const uint4 *ha = reinterpret_cast<const uint4 *>(tile_hmax + (int64_t)bi * kBins);
+            const uint4 *hb = reinterpret_cast<const uint4 *>(tile_hmax + (int64_t)bj * kBins);
+            uint32_t u = 0;
+#pragma unroll 4
+            for (int q = 0; q < kBins / 4; ++q) {
+                const uint4 x = ha[q], y = hb[q];
+                u += min(x.x, y.x) + min(x.y, y.y) + min(x.z, y.z) + min(x.w, y.w);
+            }
+            const float fi = (float)u;
+            const float den = (float)amin_a + (float)amin_b - fi;
+            possible = !(den > 0.0f) || (__fdiv_rn(fi, den) > thr);
+        }
+    }
+    const uint64_t bal = __ballot(possible);
+    if (!bal) return;
+    const int lane = lane_id();
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, __popcll(bal));
+    base = __shfl(base, 0);
+    if (possible) list[base + __popcll(bal & ((1ull << lane) - 1))] = t;
+}
+
+__device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restrict__ rows, int n, int64_t nw,
+                                                const int32_t *__restrict__ order,
+                                                const uint64_t *__restrict__ tmask, int mw,
+                                                const uint32_t *__restrict__ hist, int n_pos,
+                                                const int32_t *__restrict__ area,
+                                                const int32_t *__restrict__ label_id, float thr,
+                                                int32_t *__restrict__ parent, int n_tiles,
+                                                int32_t *__restrict__ diag)
 {
     __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
     __shared__ uint16_t clist[kMaxChunks];
     __shared__ int s_cnt;
     __shared__ int rowA[kT], rowB[kT], rootA[kT], rootB[kT];
-    int t = blockIdx.x, d = 0;
-    while (t >= n_tiles - d) { t -= n_tiles - d; ++d; }           // d = bj - bi
-    const int bi = t, bj = t + d;
+    int bi, d;
+    tile_pair_of(t, n_tiles, bi, d);
+    const int bj = bi + d;
     const int i0 = bi * kT, j0 = bj * kT;
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
     const int n_chunks = (int)((nw + kCW - 1) / kCW);
-
-    // tile-level quick reject: every pair of the tile has I <= u = sum_b min(maxA[b], maxB[b]) and
-    // a_i + a_j >= aminA + aminB, hence IoU = I / (a_i + a_j - I) <= u / (aminA + aminB - u) whenever that
-    // denominator is positive (float32 evaluation is monotone in both arguments); otherwise no conclusion.
-    {
-        const int lane = tid & 63;
-        uint32_t u = min(tile_hmax[(int64_t)bi * kBins + lane], tile_hmax[(int64_t)bj * kBins + lane]);
-#pragma unroll
-        for (int q = 32; q > 0; q >>= 1) u += __shfl_xor(u, q);
-        const int amin_a = tile_amin[bi], amin_b = tile_amin[bj];
-        bool possible = false;
-        if (amin_a != 0x7fffffff && amin_b != 0x7fffffff) {         // a tile of empty rows has no edges at all
-            const float fi = (float)u;
-            const float den = (float)amin_a + (float)amin_b - fi;
-            possible = !(den > 0.0f) || (__fdiv_rn(fi, den) > thr);
-        }
-        if (!possible) return;                                     // block-uniform: every wave computes the same
-    }
 
     if (tid < kT) {
         const int r = i0 + tid;
@@ -780,6 +813,25 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
                     if (diag) atomicAdd(diag + 3, 1);
                 }
             }
+}
+
+// Tile pass over the filtered list: block b takes entry b; blocks beyond the list (its length is only known on
+// the device) leave at once, without the loads and the reduction of the tile-level bound.  (A grid-stride or
+// work-queue loop around the tile pair costs 60-80 registers and a third of the occupancy: measured slower.)
+__global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
+                                                                const int32_t *__restrict__ order,
+                                                                const uint64_t *__restrict__ tmask, int mw,
+                                                                const uint32_t *__restrict__ hist, int n_pos,
+                                                                const int32_t *__restrict__ area,
+                                                                const int32_t *__restrict__ label_id, float thr,
+                                                                int32_t *__restrict__ parent, int n_tiles,
+                                                                int32_t *__restrict__ diag,
+                                                                const int32_t *__restrict__ list,
+                                                                const int32_t *__restrict__ count)
+{
+    if ((int)blockIdx.x >= *count) return;                         // block-uniform
+    merge_tile_pair(list[blockIdx.x], rows, n, nw, order, tmask, mw, hist, n_pos, area, label_id, thr, parent, n_tiles,
+                    diag);
 }
 
 // out bit o of row r = in bit idx[o] of row r  (bit gather; undoes the spatial point sort)
@@ -1234,9 +1286,16 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
         dim3 sgrid((unsigned)ceil_div(n_order, 4), kStrides);
         uf_skeleton_kernel<<<sgrid, 256, 0, st>>>(rows, n_order, nw, order, chunk_mask, mw, area, label_id, iou_thres,
                                                   parent, kStrides);
-        merge_components_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, st>>>(
+        const int64_t total = (int64_t)nt * (nt + 1) / 2;
+        int32_t *pair_count = tile_amin + nt;                          // behind the other scratch: count, then the list
+        int32_t *pair_list = pair_count + 1;
+        hipError_t e = hipMemsetAsync(pair_count, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) return fail((int)e, "bff_merge_components: memset: %s", hipGetErrorString(e));
+        tile_pair_filter_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(tile_hmax, tile_amin, nt, (int)total,
+                                                                               iou_thres, pair_list, pair_count);
+        merge_components_kernel<<<(unsigned)total, 256, 0, st>>>(
             rows, n_order, nw, order, sparse ? tile_mask : nullptr, mw, hist_sorted, nt * kT, area, label_id, iou_thres,
-            parent, nt, tile_hmax, tile_amin, diag);
+            parent, nt, diag, pair_list, pair_count);
     }
     if (comp) uf_flatten_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows, comp);
     return launched("bff_merge_components");

@@ -185,7 +185,7 @@ int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const 
  * i's component.  Rows with an empty
  * adjacency row (area 0, or thr >= 1) form singleton components here; the host turns them into the
  * reference's empty lists (it knows area and thr).  All other arguments as for bff_merge_adjacency;
- * chunk_mask, tile_mask and hist are required; hist_sorted is scratch, uint32 [64*64*nt + 65*nt] with
+ * chunk_mask, tile_mask and hist are required; hist_sorted is scratch, uint32 [64*64*nt + 65*nt + 1 + nt*(nt+1)/2] with
  * nt = ceil(n_rows/64);
  * diag (optional, NULL in production): int32 [4], zeroed by the caller, += {tile pairs evaluated, chunks
  * visited, candidate pairs tested exactly, unions performed}. */
