@@ -204,8 +204,8 @@ def bench_cosine(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--shape", default="c2", choices=list(SHAPES) + ["c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stagewise", action="store_true",
@@ -328,7 +328,7 @@ def main():
     if not args.no_pipeline:
         was = args.no_pipeline
         args.no_pipeline = True
-        run_steps(min(5, args.steps), seq_timers)
+        run_steps(min(10, args.steps), seq_timers)
         args.no_pipeline = was
         fence()
 
