@@ -49,10 +49,11 @@ QUERY = "table"
 def algorithmic_bytes(ds, n_frames_swept):
     """SURVEY.md section 8(d) per-unit figures for one fused sweep: 24 B xyz + 4 B depth per (frame, point);
     ceil(M/8) B mask-word gather per (mask-frame, point); the two int32 counters read+written once (16 N) --
-    that is what project_views_kernel moves -- and every instance bit written once (V*M*N/8), which here is the
-    zero-fill of the rows that precedes the kernel (the kernel itself stores only the 32-B sectors that receive
-    a point).  Each (frame, point) is counted once although the launch serves both the mask sweep and the
-    viewed sweep of the reference.  Returns (bytes of the kernel, bytes of the row zero-fill)."""
+    that is what project_views_kernel moves.  SURVEY's fourth term, every instance bit written once (V*M*N/8),
+    is not moved at all any more: the rows are a recycled zero arena, the kernel stores only the 32-B sectors
+    that receive a point (~1 %) and the back half clears exactly those; it is returned separately and NOT
+    credited to the kernel.  Each (frame, point) is counted once although the launch serves both the mask
+    sweep and the viewed sweep of the reference.  Returns (bytes of the kernel, SURVEY's row-write term)."""
     n = ds.n_points
     mask_word = ds.word_bits // 8
     return (n_frames_swept * n * 28 + ds.n_mask_frames * n * mask_word + 16 * n, ds.n_rows * n // 8)
@@ -338,13 +339,6 @@ def main():
         pv = ks["project_views"]
         abytes, zbytes = algorithmic_bytes(ds, n_swept)
         achieved = abytes / (pv[2] * 1e-3) / 1e9
-        zr = ks.get("zero_rows")
-
-        def with_fill(t_kernel, t_fill):
-            """kernel + the row zero-fill before it, against the whole SURVEY 8(d) byte count"""
-            t = t_kernel + t_fill
-            return {"ms": t, "bytes": abytes + zbytes, "achieved": (abytes + zbytes) / (t * 1e-3) / 1e9,
-                    "frac": (abytes + zbytes) / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
@@ -366,11 +360,10 @@ def main():
                          "traffic": traffic["bytes"] if traffic else None,      # HBM bytes per launch from the PMC counters
                          "traffic_detail": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": pv[2], "launches": pv[0],
-                         "with_row_zero_fill": with_fill(pv[2], zr[2]) if zr else None,
+                         "survey_row_write_bytes_not_credited": zbytes,
                          "alone_on_chip": (lambda sq: {"avg_launch_ms": sq["project_views"][2],
                                                        "achieved": abytes / (sq["project_views"][2] * 1e-3) / 1e9,
-                                                       "frac": abytes / (sq["project_views"][2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                       "with_row_zero_fill": with_fill(sq["project_views"][2], sq["zero_rows"][2])})(
+                                                       "frac": abytes / (sq["project_views"][2] * 1e-3) / 1e9 / HBM_PEAK_GBS})(
                              seq_timers.summary()) if not args.no_pipeline else None},
             "host_ms": host_ms,      # wall time of the host thread per step: issuing the front half, the back half, and the part of the back half spent blocked on the GPU
             "kernels_ms": {k: round(vv[2], 4) for k, vv in ks.items()},   # HIP-event spans (merge_components includes its read-back)

@@ -26,6 +26,7 @@ SIGNATURES = {
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
     "bff_row_stats": [_P, _I, _L, _P, _P, _P, _I, _P, _P, _P],
+    "bff_clear_flagged_chunks": [_P, _I, _L, _P, _P],
     "bff_merge_components": [_P, _I, _L, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P],
     "bff_merge_adjacency": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "bff_permute_bits": [_P, _I, _L, _P, _L, _L, _P, _P],
@@ -184,6 +185,43 @@ def cross_popcount(a, b, ia=None, ib=None):
 def chunk_mask_buffer(n_rows, nw, device):
     """Uninitialised chunk occupancy masks i64 [n_rows][mw] (zero them before handing them to project_views)."""
     return torch.empty((n_rows, max(load().bff_chunk_mask_words(nw), 1)), dtype=i64, device=device)
+
+
+class RowArena:
+    """Zero-filled instance rows without a zero-fill per scene.  One flat int64 buffer per stream that is all zero
+    whenever it is free: `take` hands out a [n_rows][nw] view of it, `release` zeroes exactly the chunks the sweep
+    flagged (bff_clear_flagged_chunks, ~1 % of the buffer) on the same stream.  A buffer that was taken and never
+    released (an exception, a caller that only runs the front half) is simply dropped: the next `take` starts from
+    fresh zeros, so a dirty buffer can never be handed out."""
+    _arenas = {}
+
+    def __init__(self):
+        self.buf = None
+        self.busy = False
+
+    @classmethod
+    def for_current_stream(cls, device):
+        st = _stream_cache[1] if _stream_cache is not None else torch.cuda.current_stream(device)
+        key = (st.device.index, st.cuda_stream)
+        a = cls._arenas.get(key)
+        if a is None:
+            a = cls._arenas[key] = cls()
+        return a
+
+    def take(self, n_rows, nw, device):
+        need = n_rows * nw
+        if self.busy or self.buf is None or self.buf.numel() < need:
+            self.buf = torch.zeros(max(need, 1), dtype=i64, device=device)      # fresh zeros (first use, growth, or dirty)
+        self.busy = True
+        return self.buf[:need].view(n_rows, nw)
+
+    def release(self, rows, cmask):
+        """rows: the view handed out by take(); cmask: the chunk flags the sweep wrote for it."""
+        if not self.busy or self.buf is None or rows.data_ptr() != self.buf.data_ptr():
+            return                                                  # not ours (any more): nothing to recycle
+        if rows.numel():
+            call("bff_clear_flagged_chunks", _ptr(rows, i64), rows.shape[0], rows.shape[1], _ptr(cmask, i64))
+        self.busy = False
 
 
 def row_stats(rows, cmask=None):

@@ -220,6 +220,26 @@ __global__ __launch_bounds__(256) void row_stats_sparse_kernel(const uint64_t *_
     }
 }
 
+// Undo what the sweep stored: zero exactly the chunks flagged in the rows' occupancy masks (one wave per row), so
+// that a zero-filled row arena is all zero again after a scene without touching its other 99 %.
+__global__ __launch_bounds__(256) void clear_flagged_chunks_kernel(uint64_t *__restrict__ rows, int n_rows, int64_t nw,
+                                                                    const uint64_t *__restrict__ cmask, int mw)
+{
+    const int lane = lane_id();
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    uint64_t *row = rows + (int64_t)r * nw;
+    for (int i = 0; i < mw; ++i) {
+        const uint64_t m = cmask[(int64_t)r * mw + i];
+        if ((m >> lane) & 1) {
+            const int64_t w0 = ((int64_t)i * 64 + lane) * kCW;
+#pragma unroll
+            for (int k = 0; k < kCW; ++k)
+                if (w0 + k < nw) row[w0 + k] = 0;
+        }
+    }
+}
+
 // Per tile t (rows order[64t .. 64t+63]): tmask[t] = OR of the rows' chunk masks; optionally the sorted,
 // packed histogram copy hist_sorted[bin pair][position] (two 16-bit bins per word: coalesced tile loads, one
 // v_pk_min_u16 + v_dot2_u32_u16 per two bins), the bin-wise maxima and the smallest non-empty area of the tile.
@@ -1231,6 +1251,17 @@ extern "C" int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, i
 }
 
 extern "C" int bff_chunk_mask_words(int64_t nw) { return (int)ceil_div(ceil_div(nw, kCW), 64); }
+
+extern "C" int bff_clear_flagged_chunks(uint64_t *rows, int32_t n_rows, int64_t nw, const uint64_t *chunk_mask,
+                                        void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_clear_flagged_chunks: bad sizes");
+    if (n_rows == 0 || nw == 0) return BFF_OK;
+    BFF_REQUIRE(rows && chunk_mask, "bff_clear_flagged_chunks: null pointer");
+    clear_flagged_chunks_kernel<<<(unsigned)ceil_div(n_rows, 4), 256, 0, as_stream(stream)>>>(
+        rows, n_rows, nw, chunk_mask, (int)ceil_div(ceil_div(nw, kCW), 64));
+    return launched("bff_clear_flagged_chunks");
+}
 
 extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
                                    const uint64_t *chunk_mask, uint64_t *tile_mask, const uint32_t *hist,

@@ -165,6 +165,8 @@ class _Front:
     lat_info: Optional[torch.Tensor] = None
     area: Optional[torch.Tensor] = None
     comp: Optional[torch.Tensor] = None
+    cmask: Optional[torch.Tensor] = None       # chunk occupancy flags of `rows` (what the sweep stored into)
+    arena: Optional[object] = None             # _lib.RowArena that lent `rows` (None: a tensor of its own)
     do_ratio: bool = False
 
 
@@ -193,13 +195,19 @@ def _projection_front(ds, cfg, debug_out, timers) -> _Front:
                              ds.height * ds.width, ds.word_bits, maskbits, segmap)
 
     # a2-a8 (+a15): one fused sweep over the frames (P:413-461 and P:538-567)
-    with span(timers, "zero_rows"):       # the sweep stores only the sectors that receive a point
-        rows = fr.rows = torch.zeros((ds.n_rows, nw), dtype=torch.int64, device=dev)
+    # the sweep stores only the sectors that receive a point, so the rows start out zero: a view of the stream's
+    # recycled zero arena (the back half clears what this scene stored), fresh zeros when the rows are handed out
+    with span(timers, "zero_rows"):
+        if ds.n_rows and n_mviews and not debug_out:
+            fr.arena = _lib.RowArena.for_current_stream(dev)
+            rows = fr.rows = fr.arena.take(ds.n_rows, nw, dev)
+        else:
+            rows = fr.rows = torch.zeros((ds.n_rows, nw), dtype=torch.int64, device=dev)
     masked = fr.masked = torch.zeros(n, dtype=torch.int32, device=dev)                          # P:402
     viewed = fr.viewed = torch.zeros(n, dtype=torch.int32, device=dev) if do_ratio else None    # P:537
     n_frames = ds.n_frames if do_ratio else ds.n_mask_frames
     # the sweep flags, per row, the 512-point chunks it stores into: the later passes read nothing else
-    cmask_in = _lib.chunk_mask_buffer(ds.n_rows, nw, dev).zero_() if (ds.n_rows and n_mviews) else None
+    cmask_in = fr.cmask = _lib.chunk_mask_buffer(ds.n_rows, nw, dev).zero_() if (ds.n_rows and n_mviews) else None
     with sweep_span(timers, "project_views"):
         _lib.project_views(ds.xyz, n, ds.inv_pose[:n_frames], ds.cam_intr, ds.depth, ds.depth_index, ds.height,
                            ds.width, DEPTH_THRESH, maskbits if n_mviews else None, ds.word_bits, ds.frame_mask,
@@ -255,6 +263,13 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, p
     return projection_back(fr, timers, phases, stage1)
 
 
+def _recycle_rows(fr: _Front):
+    """Hand the raw rows back: a borrowed arena view is cleared where the sweep stored (stream-ordered)."""
+    if fr.arena is not None and fr.rows is not None:
+        fr.arena.release(fr.rows, fr.cmask)
+    fr.rows = fr.arena = None
+
+
 def _projection_back(fr: _Front, timers, phases, stage1=None) -> Stage2Result:
     import time
     _t = [time.perf_counter()]
@@ -298,6 +313,7 @@ def _projection_back(fr: _Front, timers, phases, stage1=None) -> Stage2Result:
     k_groups = sizes.shape[0]
     if k_groups == 0:                                                               # P:230-236, 496-509
         dbg["groups"] = [] if groups is None else groups
+        _recycle_rows(fr)
         return _empty(ds, dbg)
 
     # a13: OR of member rows, sequential mean of confidences, label of the first member (P:214-226)
@@ -310,7 +326,7 @@ def _projection_back(fr: _Front, timers, phases, stage1=None) -> Stage2Result:
     agg_labels = [ds.labels[i] for i in first_member]
     if not debug_out:
         del rows
-        fr.rows = None
+        _recycle_rows(fr)                         # last reader done: the arena gets its zeros back
     mark("grouping+or_reduce")
 
     # a16: overlap resolution (P:592-596), decided and applied on the device

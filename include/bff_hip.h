@@ -149,6 +149,11 @@ int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *are
                   uint64_t *chunk_mask, int32_t chunk_mask_given, uint32_t *hist, int64_t *signature, void *stream);
 int bff_chunk_mask_words(int64_t nw);
 
+/* rows[r][chunk c] = 0 for every chunk flagged in chunk_mask (as written by bff_project_views): returns a
+ * zero-filled row buffer to all-zero after a scene at the cost of the ~1 % of it that was ever stored, so the
+ * buffer can serve the next scene without another full zero-fill. */
+int bff_clear_flagged_chunks(uint64_t *rows, int32_t n_rows, int64_t nw, const uint64_t *chunk_mask, void *stream);
+
 /* a9-a11: merge adjacency of `aggregate` P:100-146.  For every pair (i, j):
  *   I = popcount(rows[i] & rows[j]);  iou = (float)I / ((float)area[i] + (float)area[j] - (float)I)
  *   (IEEE float32 division; 0/0 = NaN compares false, P:149-166);

@@ -176,6 +176,18 @@ def test_project_views_random_vs_c_oracle(lib):
         assert vis.sum() > 1000
 
 
+def test_clear_flagged_chunks(lib):
+    rng = np.random.default_rng(11)
+    n = 5 * 512 + 77                                            # ragged last chunk
+    d = random_rows(rng, 9, n, 0.01)
+    d[:, 1024:1536] = False                                     # a chunk nobody occupies
+    rows = pack_np(d)
+    cm = lib.row_stats(rows)[2]
+    untouched = rows.clone()
+    lib.call("bff_clear_flagged_chunks", lib._ptr(rows, torch.int64), rows.shape[0], rows.shape[1], lib._ptr(cm, torch.int64))
+    assert int(rows.count_nonzero()) == 0 and int(untouched.count_nonzero()) > 0
+
+
 # ------------------------------------------------------------------ bit-row primitives
 def random_rows(rng, r, n, p=0.1):
     d = rng.random((r, n)) < p

@@ -195,6 +195,32 @@ def test_refinement_merge_branches(api, variant):
     same(got["s_00"].to_dict(), exp["s_00"])
 
 
+def test_row_arena_recycling(api):
+    """The instance rows of the non-debug path are a view of a per-stream zero arena that the back half clears
+    sparsely.  Several scenes of different shapes through the same arena, a front half whose back half never runs
+    (arena left dirty: must be dropped, not reused) and the plain-tensor debug path all give the same results."""
+    projection, _ = api
+    from beyond_fixed_forms_amd import _lib
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    from beyond_fixed_forms_amd.synthetic import make_scene
+    scenes = [make_scene("tiny", seed=31), make_scene("tiny", seed=32, n_points=4001, n_masks=40), make_scene("c1", seed=33)]
+    ref = []
+    for sc in scenes:
+        cfg = cfg_for(sc)
+        ref.append(projection.run_projection(prepare_scene(sc, cfg, device=DEV), cfg, debug_out=True))    # own tensors
+    arena = _lib.RowArena.for_current_stream(torch.device(DEV))
+    for rnd in range(2):
+        for sc, exp in zip(scenes, ref):
+            cfg = cfg_for(sc)
+            ds = prepare_scene(sc, cfg, device=DEV)
+            if rnd == 1 and sc is scenes[1]:
+                projection.projection_front(ds, cfg)                 # abandoned: its rows stay dirty in the arena
+                assert arena.busy
+            got = projection.run_projection(ds, cfg)
+            assert not arena.busy and (arena.buf is None or int(arena.buf.count_nonzero()) == 0)
+            assert torch.equal(got.rows, exp.rows) and torch.equal(got.conf, exp.conf) and got.groups == exp.groups
+
+
 def test_raw_depth_path_equals_float_depth_path(api):
     """A scene given as raw uint16 depth at sensor resolution (scaled + resized on the device) gives the same
     result as the same scene with the depth resized on the host (io.resize_bilinear_f32)."""
