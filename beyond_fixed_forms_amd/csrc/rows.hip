@@ -614,6 +614,17 @@ __global__ __launch_bounds__(256) void tile_pair_filter_kernel(const uint32_t *_
     if (possible) list[base + __popcll(bal & ((1ull << lane) - 1))] = t;
 }
 
+// diagnostics only: thread 0 adds the cycles since *t0 to diag[slot] (>> 6 to stay inside int32) and restarts the clock
+__device__ __forceinline__ void diag_lap(int32_t *diag, int slot, long long *t0)
+{
+    if (diag && threadIdx.x == 0) {
+        const long long now = (long long)__builtin_readcyclecounter();
+        atomicAdd(diag + slot, (int)((now - *t0) >> 6));
+        *t0 = now;
+    }
+}
+
+template <bool kDiag>
 __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restrict__ rows, int n, int64_t nw,
                                                 const int32_t *__restrict__ order,
                                                 const uint64_t *__restrict__ tmask, int mw,
@@ -621,27 +632,43 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
                                                 const int32_t *__restrict__ area,
                                                 const int32_t *__restrict__ label_id, float thr,
                                                 int32_t *__restrict__ parent, int n_tiles,
+                                                const uint32_t *__restrict__ tile_hmax,
+                                                const int32_t *__restrict__ tile_amin,
                                                 int32_t *__restrict__ diag)
 {
     __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
     __shared__ uint16_t clist[kMaxChunks];
     __shared__ int s_cnt;
     __shared__ int rowA[kT], rowB[kT], rootA[kT], rootB[kT];
+    __shared__ int areaA[kT], areaB[kT], labA[kT], labB[kT];       // fetched once per tile pair, next to the roots
+    __shared__ uint32_t hmaxA[kBins], hmaxB[kBins];                // bin-wise maxima of the two tiles
+    __shared__ uint8_t passA[kT], passB[kT];                       // row can still have an edge into the other tile
     int bi, d;
     tile_pair_of(t, n_tiles, bi, d);
     const int bj = bi + d;
     const int i0 = bi * kT, j0 = bj * kT;
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
     const int n_chunks = (int)((nw + kCW - 1) / kCW);
+    long long t_lap = kDiag ? (long long)__builtin_readcyclecounter() : 0;     // kDiag: counters + phase clocks
 
     if (tid < kT) {
         const int r = i0 + tid;
-        rowA[tid] = r < n ? (order ? order[r] : r) : -1;
-        rootA[tid] = rowA[tid] >= 0 ? uf_find(parent, rowA[tid]) : -1;
+        const int row = r < n ? (order ? order[r] : r) : -1;
+        rowA[tid] = row;
+        areaA[tid] = row >= 0 ? area[row] : 0;
+        labA[tid] = row >= 0 ? label_id[row] : -1;
+        rootA[tid] = row >= 0 ? uf_find(parent, row) : -1;
     } else if (tid < 2 * kT) {
         const int r = j0 + tid - kT;
-        rowB[tid - kT] = r < n ? (order ? order[r] : r) : -1;
-        rootB[tid - kT] = rowB[tid - kT] >= 0 ? uf_find(parent, rowB[tid - kT]) : -2;
+        const int row = r < n ? (order ? order[r] : r) : -1;
+        rowB[tid - kT] = row;
+        areaB[tid - kT] = row >= 0 ? area[row] : 0;
+        labB[tid - kT] = row >= 0 ? label_id[row] : -2;
+        rootB[tid - kT] = row >= 0 ? uf_find(parent, row) : -2;
+    } else if (tid < 3 * kT) {
+        hmaxA[tid - 2 * kT] = tile_hmax[(int64_t)bi * kBins + tid - 2 * kT];
+    } else {
+        hmaxB[tid - 3 * kT] = tile_hmax[(int64_t)bj * kBins + tid - 3 * kT];
     }
     // histogram bound (see merge_adjacency_kernel): possible edges only.  hist holds two 16-bit bins per
     // word, so one v_pk_min_u16 + one v_dot2_u32_u16 accumulates two bins of sum_b min(hist_i, hist_j).
@@ -658,6 +685,37 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
         }
     }
     __syncthreads();
+    if (kDiag) diag_lap(diag, 4, &t_lap);                                     // roots + histogram staging
+    // row-level bound, between the tile-level one and the pair-level one: row i of A against the bin-wise maxima
+    // of tile B, I(i, j) <= sum_b min(h_i[b], maxB[b]) for every j of B and a_j >= aminB (and the mirror image).
+    // Rows that fail cannot have an edge into the other tile; most listed tile pairs end here.
+    {
+        bool pass = false;
+        if (tid < 2 * kT) {
+            const bool is_a = tid < kT;
+            const int k = is_a ? tid : tid - kT;
+            const int row = is_a ? rowA[k] : rowB[k];
+            if (row >= 0) {
+                const uint32_t *other = is_a ? hmaxB : hmaxA;
+                uint32_t u = 0;
+#pragma unroll 8
+                for (int b = 0; b < kBP; ++b) {
+                    const uint32_t w = is_a ? ha[b][k] : hb[b][k];
+                    u += min(w & 0xffffu, other[2 * b]) + min(w >> 16, other[2 * b + 1]);
+                }
+                const int a_self = is_a ? areaA[k] : areaB[k];
+                const int a_other = is_a ? tile_amin[bj] : tile_amin[bi];
+                const float fi = (float)min((int)u, a_self);
+                const float den = (float)a_self + (float)a_other - fi;
+                pass = !(den > 0.0f) || (__fdiv_rn(fi, den) > thr);
+            }
+            if (is_a) passA[k] = pass; else passB[k] = pass;
+        }
+        const int any_a = __syncthreads_or(pass && tid < kT);
+        const int any_b = __syncthreads_or(pass && tid >= kT);
+        if (kDiag) diag_lap(diag, 11, &t_lap);                     // row-level bound
+        if (!any_a || !any_b) return;                              // block-uniform
+    }
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     uint32_t ub[4][4];
 #pragma unroll
@@ -665,6 +723,9 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) ub[r][c] = 0;
     const us2 ones = {1, 1};
+    const uint32_t mine_a = *reinterpret_cast<const uint32_t *>(&passA[ti * 4]);     // 4 flags each
+    const uint32_t mine_b = *reinterpret_cast<const uint32_t *>(&passB[tj * 4]);
+    if (mine_a && mine_b)
 #pragma unroll 4
     for (int b = 0; b < kBP; ++b) {
         uint32_t av[4], bv[4];
@@ -684,14 +745,16 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int i = rowA[ti * 4 + r], j = rowB[tj * 4 + c];
-            if (i >= 0 && j >= 0 && i != j && rootA[ti * 4 + r] != rootB[tj * 4 + c] && (d > 0 || ti * 4 + r < tj * 4 + c)) {
-                const int ai = area[i], aj = area[j];
+            if (((mine_a >> (8 * r)) & 1) && ((mine_b >> (8 * c)) & 1) && i >= 0 && j >= 0 && i != j &&
+                rootA[ti * 4 + r] != rootB[tj * 4 + c] && (d > 0 || ti * 4 + r < tj * 4 + c)) {
+                const int ai = areaA[ti * 4 + r], aj = areaB[tj * 4 + c];
                 const float fi = (float)min((int)ub[r][c], min(ai, aj));
                 const float iou = __fdiv_rn(fi, (float)ai + (float)aj - fi);
-                if ((label_id[i] == label_id[j]) && (iou > thr)) cand |= 1u << (4 * r + c);
+                if ((labA[ti * 4 + r] == labB[tj * 4 + c]) && (iou > thr)) cand |= 1u << (4 * r + c);
             }
         }
     const int any_candidate = __syncthreads_or(cand != 0);
+    if (kDiag) diag_lap(diag, 5, &t_lap);                                     // per-pair histogram bound
     if (!any_candidate) return;                                    // block-uniform
 
     // ---- compact the candidate pairs of the tile: (row index in A) << 8 | (row index in B)
@@ -729,7 +792,7 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
     }
     __syncthreads();
     const int cnt = s_cnt;
-    if (diag) {                                                    // diagnostics only (NULL in production)
+    if (kDiag) {                                                   // diagnostics only
         if (tid == 0) { atomicAdd(diag + 0, 1); atomicAdd(diag + 1, cnt); atomicAdd(diag + 2, n_pairs); }
     }
     const int lk = tid & (kKW - 1), lr = tid >> 5;
@@ -760,6 +823,7 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
     };
     constexpr int kStep = kKW / kCW;                               // chunks per stage
     constexpr int kSparse = 3;                                     // pair-list path: at most 3 pairs per thread
+    if (kDiag) diag_lap(diag, 6, &t_lap);                                     // pair / chunk lists
     if (cnt) fetch(0);
     if (n_pairs <= kSparse * 256) {
         // few candidates: accumulate only those pairs (2 LDS reads per pair word)
@@ -790,12 +854,14 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
             if (q < n_mine) {
                 const int i = rowA[pi[q]], j = rowB[pj[q]];
                 const float fi = (float)accs[q];
-                const float iou = __fdiv_rn(fi, (float)area[i] + (float)area[j] - fi);   // P:149-166
+                const float iou = __fdiv_rn(fi, (float)areaA[pi[q]] + (float)areaB[pj[q]] - fi);   // P:149-166
                 if (iou > thr) {
                     uf_union(parent, i, j);
-                    if (diag) atomicAdd(diag + 3, 1);
+                    if (kDiag) atomicAdd(diag + 3, 1);
                 }
             }
+        if (kDiag) diag_lap(diag, 7, &t_lap);                                 // pair-list pass (incl. its unions)
+        if (kDiag && tid == 0) atomicAdd(diag + 9, 1);
         return;
     }
     // many candidates: full 4x4 register blocks
@@ -827,17 +893,20 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
             if (cand & (1u << (4 * r + c))) {
                 const int i = rowA[ti * 4 + r], j = rowB[tj * 4 + c];
                 const float fi = (float)acc[r][c];
-                const float iou = __fdiv_rn(fi, (float)area[i] + (float)area[j] - fi);   // P:149-166
+                const float iou = __fdiv_rn(fi, (float)areaA[ti * 4 + r] + (float)areaB[tj * 4 + c] - fi);   // P:149-166
                 if (iou > thr) {                                                         // labels already equal
                     uf_union(parent, i, j);
-                    if (diag) atomicAdd(diag + 3, 1);
+                    if (kDiag) atomicAdd(diag + 3, 1);
                 }
             }
+    if (kDiag) diag_lap(diag, 8, &t_lap);                                     // dense pass (incl. its unions)
+    if (kDiag && tid == 0) atomicAdd(diag + 10, 1);
 }
 
 // Tile pass over the filtered list: block b takes entry b; blocks beyond the list (its length is only known on
 // the device) leave at once, without the loads and the reduction of the tile-level bound.  (A grid-stride or
 // work-queue loop around the tile pair costs 60-80 registers and a third of the occupancy: measured slower.)
+template <bool kDiag>
 __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
                                                                 const int32_t *__restrict__ order,
                                                                 const uint64_t *__restrict__ tmask, int mw,
@@ -845,13 +914,22 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
                                                                 const int32_t *__restrict__ area,
                                                                 const int32_t *__restrict__ label_id, float thr,
                                                                 int32_t *__restrict__ parent, int n_tiles,
+                                                                const uint32_t *__restrict__ tile_hmax,
+                                                                const int32_t *__restrict__ tile_amin,
                                                                 int32_t *__restrict__ diag,
                                                                 const int32_t *__restrict__ list,
                                                                 const int32_t *__restrict__ count)
 {
     if ((int)blockIdx.x >= *count) return;                         // block-uniform
-    merge_tile_pair(list[blockIdx.x], rows, n, nw, order, tmask, mw, hist, n_pos, area, label_id, thr, parent, n_tiles,
-                    diag);
+    long long t_start = 0;
+    if (kDiag) t_start = (long long)__builtin_amdgcn_s_memrealtime();    // 100 MHz, one clock for the whole chip
+    merge_tile_pair<kDiag>(list[blockIdx.x], rows, n, nw, order, tmask, mw, hist, n_pos, area, label_id, thr, parent, n_tiles,
+                           tile_hmax, tile_amin, diag);
+    if (kDiag && threadIdx.x == 0 && diag[15] > 0 && (int)blockIdx.x < diag[15]) {
+        // block timeline (diag[15] = capacity): start / end in 10-ns ticks (low 32 bits), at diag[16 + 2 b]
+        diag[16 + 2 * blockIdx.x] = (int32_t)t_start;
+        diag[17 + 2 * blockIdx.x] = (int32_t)(long long)__builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // out bit o of row r = in bit idx[o] of row r  (bit gather; undoes the spatial point sort)
@@ -1324,9 +1402,14 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
         if (e != hipSuccess) return fail((int)e, "bff_merge_components: memset: %s", hipGetErrorString(e));
         tile_pair_filter_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(tile_hmax, tile_amin, nt, (int)total,
                                                                                iou_thres, pair_list, pair_count);
-        merge_components_kernel<<<(unsigned)total, 256, 0, st>>>(
-            rows, n_order, nw, order, sparse ? tile_mask : nullptr, mw, hist_sorted, nt * kT, area, label_id, iou_thres,
-            parent, nt, diag, pair_list, pair_count);
+        if (diag)       // counters + phase clocks compiled in (a couple of registers more: one wave less per SIMD)
+            merge_components_kernel<true><<<(unsigned)total, 256, 0, st>>>(
+                rows, n_order, nw, order, sparse ? tile_mask : nullptr, mw, hist_sorted, nt * kT, area, label_id, iou_thres,
+                parent, nt, tile_hmax, tile_amin, diag, pair_list, pair_count);
+        else
+            merge_components_kernel<false><<<(unsigned)total, 256, 0, st>>>(
+                rows, n_order, nw, order, sparse ? tile_mask : nullptr, mw, hist_sorted, nt * kT, area, label_id, iou_thres,
+                parent, nt, tile_hmax, tile_amin, nullptr, pair_list, pair_count);
     }
     if (comp) uf_flatten_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows, comp);
     return launched("bff_merge_components");
