@@ -213,20 +213,30 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True)
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(dev)
 
     nf = len(inv)
+
+    def frames_to_device(frames, np_dtype, torch_dtype):
+        """list of equally shaped host arrays -> one device tensor [F][...], frame by frame (no 1.5 GB np.stack:
+        the copies go straight from the callers' arrays)."""
+        out = torch.empty((len(frames),) + tuple(frames[0].shape), dtype=torch_dtype, device=dev)
+        for i, f in enumerate(frames):
+            out[i].copy_(torch.from_numpy(np.ascontiguousarray(f, dtype=np_dtype)))
+        return out
+
     if raw_depth is not None and depth_list:
         from . import _lib
         from .io import bilinear_taps
-        raw = np.stack(depth_list)
-        hs, ws = raw.shape[1:]
+        hs, ws = depth_list[0].shape
+        if any(d.shape != (hs, ws) for d in depth_list):
+            raise ValueError("raw depth frames of different sizes")
         taps = None
         if (hs, ws) != (h, w):
             taps = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in bilinear_taps(hs, ws, h, w))
-        host = torch.from_numpy(raw.view(np.int16))
-        if dev.type == "cuda":
-            host = host.pin_memory()
-        depth_dev = _lib.depth_from_u16(host.to(dev, non_blocking=True), h, w, taps)
+        raw_dev = frames_to_device([d.view(np.int16) for d in depth_list], np.int16, torch.int16)
+        depth_dev = _lib.depth_from_u16(raw_dev, h, w, taps)
+    elif depth_list:
+        depth_dev = frames_to_device(depth_list, np.float32, torch.float32)
     else:
-        depth_dev = t(np.stack(depth_list) if depth_list else np.zeros((0, h * w), np.float32), torch.float32)
+        depth_dev = torch.zeros((0, h * w), dtype=torch.float32, device=dev)
     return DeviceScene(
         scene_id=scene.scene_id, n_points=n, nw=nw, height=h, width=w, cam_intr=cam_intr,
         xyz=t(soa, torch.float64),
