@@ -48,6 +48,7 @@ SIGNATURES = {
     "bff_point_values": [_P, _P, _L, _P, _P],
     "bff_select_unique_rank": [_P, _L, _D, _P, _P, _P, _P],
     "bff_cosine_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
+    "bff_cosine_rows": [_P, _I, _P, _I, _I, _I, _P, _P],
     "bff_sort_f32": [_P, _P, _L, _P, _P, _P],
     "bff_argsort_i64": [_P, _P, _P, _I, _I, _P, _P, _P],
     "bff_depth_from_u16": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P],
@@ -57,7 +58,7 @@ PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, [
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
          "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
          "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class BffLibraryError(RuntimeError):
@@ -586,4 +587,17 @@ def cosine_gemm_f16(a, b):
         raise TypeError("cosine_gemm_f16 takes float16 operands")
     out = torch.empty((a.shape[0], b.shape[0]), dtype=f32, device=a.device)
     call("bff_cosine_gemm_f16", _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], _ptr(out))
+    return out
+
+
+def cosine_rows(a, b):
+    """cos[i][j] of float16 or float32 embedding rows, rounded op by op in that dtype like the reference's
+    tensor expression (R:109-114) -> float32 [na][nb] (float16 values when the inputs are float16)."""
+    if a.dtype != b.dtype or a.dtype not in (torch.float16, torch.float32):
+        raise TypeError("cosine_rows takes two float16 or two float32 tensors")
+    if a.shape[1] != b.shape[1]:
+        raise ValueError("cosine_rows: embedding widths differ")
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=f32, device=a.device)
+    call("bff_cosine_rows", _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1],
+         1 if a.dtype == torch.float16 else 0, _ptr(out))
     return out

@@ -53,6 +53,45 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_kernel(const _Float16 *__
     }
 }
 
+
+// Cosine of every (a_i, b_j) pair IN THE DTYPE OF THE EMBEDDINGS, i.e. with the roundings of the reference's
+// tensor expression  (e1 @ e2.T) / (e1.norm() * e2.norm().T)  (compute_clip_similarity R:109-114): each of the
+// four tensor ops rounds its result to the embedding dtype.  The class threshold of the refinement is an order
+// statistic of the SET of these values (R:321-324), so the rounding decides which values tie -- with fp16
+// embeddings (CLIP on a GPU) cosines are multiples of 2^-11 and many labels collapse onto one value.
+// One wave per pair, float64 accumulation (the sums are then correctly rounded; a BLAS dot in float32 differs
+// from that by an ulp at most, which no implementation can pin across machines).  Tiny by construction:
+// <= 200 labels x a few queries.
+template <typename T>
+__global__ __launch_bounds__(256) void cosine_rows_kernel(const T *__restrict__ a, int na, const T *__restrict__ b,
+                                                           int nb, int dim, float *__restrict__ out)
+{
+    const int lane = lane_id();
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= (int64_t)na * nb) return;                     // wave-uniform
+    const int i = (int)(pair / nb), j = (int)(pair % nb);
+    const T *pa = a + (int64_t)i * dim, *pb = b + (int64_t)j * dim;
+    double dot = 0.0, sa = 0.0, sb = 0.0;
+    for (int k = lane; k < dim; k += kWave) {
+        const double x = (double)(float)pa[k], y = (double)(float)pb[k];
+        dot = fma(x, y, dot);
+        sa = fma(x, x, sa);
+        sb = fma(y, y, sb);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { dot += __shfl_xor(dot, d); sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+    if (lane) return;
+    if constexpr (sizeof(T) == 2) {
+        const _Float16 hd = (_Float16)(float)dot;                              // e1 @ e2.T          -> f16
+        const _Float16 h1 = (_Float16)(float)sqrt(sa), h2 = (_Float16)(float)sqrt(sb);   // norms -> f16
+        const _Float16 den = (_Float16)((float)h1 * (float)h2);                // norm * norm.T      -> f16
+        out[pair] = (float)(_Float16)((float)hd / (float)den);                 // sim / den          -> f16
+    } else {
+        const float fd = (float)dot, f1 = (float)sqrt(sa), f2 = (float)sqrt(sb);
+        out[pair] = __fdiv_rn(fd, __fmul_rn(f1, f2));
+    }
+}
+
 }  // namespace bff
 
 using namespace bff;
@@ -67,4 +106,19 @@ extern "C" int bff_cosine_gemm_f16(const void *a, int32_t na, const void *b, int
     dim3 grid((unsigned)ceil_div(ceil_div(nb, 16), 4), (unsigned)ceil_div(na, 16));
     cosine_gemm_f16_kernel<<<grid, 256, 0, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b, nb, dim, cos);
     return launched("bff_cosine_gemm_f16");
+}
+
+extern "C" int bff_cosine_rows(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim, int32_t dtype,
+                               float *cos, void *stream)
+{
+    BFF_REQUIRE(na >= 0 && nb >= 0 && dim > 0, "bff_cosine_rows: bad sizes");
+    BFF_REQUIRE(dtype == 0 || dtype == 1, "bff_cosine_rows: dtype 0 (float32) or 1 (float16)");
+    if (na == 0 || nb == 0) return BFF_OK;
+    BFF_REQUIRE(a && b && cos, "bff_cosine_rows: null pointer");
+    const unsigned grid = (unsigned)ceil_div((int64_t)na * nb, 4);
+    if (dtype == 1)
+        cosine_rows_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b, nb, dim, cos);
+    else
+        cosine_rows_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float *)a, na, (const float *)b, nb, dim, cos);
+    return launched("bff_cosine_rows");
 }

@@ -591,7 +591,10 @@ __global__ __launch_bounds__(256) void tile_pair_filter_kernel(const uint32_t *_
         tile_pair_of(t, n_tiles, bi, d);
         const int bj = bi + d;
         const int amin_a = tile_amin[bi], amin_b = tile_amin[bj];
-        if (amin_a != 0x7fffffff && amin_b != 0x7fffffff) {         // a tile of empty rows has no edges at all
+        // a tile of empty rows has no edges at all -- unless the threshold is negative: an empty row then links to
+        // every non-empty row of its label (IoU 0 > thr, P:149-166), and the bound below holds with amin = INT_MAX
+        // too (quotient >= 0 > thr)
+        if (0.0f > thr || (amin_a != 0x7fffffff && amin_b != 0x7fffffff)) {
             const uint4 *ha = reinterpret_cast<const uint4 *>(tile_hmax + (int64_t)bi * kBins);
             const uint4 *hb = reinterpret_cast<const uint4 *>(tile_hmax + (int64_t)bj * kBins);
             uint32_t u = 0;

@@ -168,7 +168,8 @@ def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[floa
     streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)] if torch.device(device).type == "cuda" else None
 
     def front(k):
-        ds = prepare_scene(scenes[mine[k]], cfg, device=device)
+        ds = prepare_scene(scenes[mine[k]], cfg, device=device,
+                           with_viewed=(not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold))
         if streams is None:
             return projection_front(ds, cfg)
         streams[k % 2].wait_stream(torch.cuda.current_stream())       # the upload ran on the current stream

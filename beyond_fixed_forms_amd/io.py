@@ -19,20 +19,32 @@ from .synthetic import SceneInputs
 DEPTH_SCALE = 1000            # hard-coded at P:346
 
 
-def _axis_taps(n_dst, n_src):
-    f = (np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5
+def _axis_taps(n_dst, n_src, axis):
+    """2-tap tables of one axis with the coefficient arithmetic of OpenCV's resize (INTER_LINEAR, float32
+    images; restated from memory of imgproc/resize.cpp -- cv2 is not in the build container: parity unpinned):
+    scale = 1 / (n_dst / n_src) in double; the source coordinate is CAST TO FLOAT32 before its floor is
+    subtracted (fx = (float)((dx + 0.5) * scale - 0.5); sx = floor(fx); fx -= sx);
+    x axis: sx < 0 -> (sx, fx) = (0, 0); sx >= n_src - 1 -> (n_src - 1, 0), so the border columns are copied;
+    y axis: the fraction is kept and only the two row indices are clamped into the image."""
+    scale = 1.0 / (float(n_dst) / float(n_src))
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
     i0 = np.floor(f).astype(np.int64)
-    a = (f - i0).astype(np.float32)
-    a[i0 < 0] = 0.0
-    i0 = np.clip(i0, 0, n_src - 1)
-    i1 = np.clip(i0 + 1, 0, n_src - 1)
+    a = (f - i0.astype(np.float32)).astype(np.float32)
+    if axis == "x":
+        lo, hi = i0 < 0, i0 >= n_src - 1
+        a[lo | hi] = 0.0
+        i0 = np.where(lo, 0, np.where(hi, n_src - 1, i0))
+        i1 = np.minimum(i0 + 1, n_src - 1)
+    else:
+        i1 = np.clip(i0 + 1, 0, n_src - 1)
+        i0 = np.clip(i0, 0, n_src - 1)
     return i0, i1, a
 
 
 def bilinear_taps(h_src, w_src, height, width):
     """Tap tables of the bilinear resize (x0, x1, ax, y0, y1, ay) as int32 / float32 arrays."""
-    x0, x1, ax = _axis_taps(width, w_src)
-    y0, y1, ay = _axis_taps(height, h_src)
+    x0, x1, ax = _axis_taps(width, w_src, "x")
+    y0, y1, ay = _axis_taps(height, h_src, "y")
     return (x0.astype(np.int32), x1.astype(np.int32), ax, y0.astype(np.int32), y1.astype(np.int32), ay)
 
 

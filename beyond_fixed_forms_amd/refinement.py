@@ -22,22 +22,32 @@ from .scene import runs_from_rles
 
 # --------------------------------------------------------------------------- text similarity
 class TextSimilarity:
-    """cos(query, label) for every label the class loop can meet, computed once per query with
-    bff_cosine_gemm_f16 (replaces compute_clip_similarity R:93-115, called per matched mask).
+    """cos(query, label) for every label the class loop can meet, computed once per query on the device
+    (replaces compute_clip_similarity R:93-115, called twice per matched mask).
 
-    `encode_text(str) -> (1, D) tensor` is the CLIP text encoder (or any stand-in); embeddings are
-    cast to float16 for the matrix cores, accumulation and normalisation are float32."""
+    `encode_text(str) -> (1, D) tensor` is the CLIP text encoder (or any stand-in).  The embeddings keep the
+    ENCODER'S dtype -- float16 (CLIP on a GPU, what the reference's recorded run used) or float32 (CLIP on the
+    CPU; anything else is widened to float32) -- and bff_cosine_rows rounds every tensor op of R:109-114 to that
+    dtype, because the class threshold is an order statistic of the *set* of these values (R:321-324): with
+    fp16 embeddings the cosines are multiples of 2^-11 and ties collapse, which moves the index.  Against the
+    reference on the same embeddings the values agree to the last bit except where its float32 BLAS dot sits
+    on a rounding boundary (<= 1 ulp of the dtype; tolerance of north_star: 1e-4)."""
 
     def __init__(self, encode_text: Callable[[str], torch.Tensor], device="cuda", labels: Sequence[str] = SCANNET200_LABELS):
         self.device = torch.device(device)
         self.labels = list(labels)
         with torch.no_grad():
-            bank = torch.cat([encode_text(lab).reshape(1, -1) for lab in self.labels]).to(torch.float16)
-        self.bank = self._pad(bank).to(self.device).contiguous()
+            rows = [encode_text(lab).reshape(1, -1) for lab in self.labels]
+        self.dtype = self._dtype_of(rows[0])
+        self.bank = torch.cat(rows).to(self.dtype).to(self.device).contiguous()
         self.encode_text = encode_text
         self.index = {lab: i for i, lab in enumerate(self.labels)}
         self._cache: Dict[str, np.ndarray] = {}
         self._query_emb: Dict[str, torch.Tensor] = {}
+
+    @staticmethod
+    def _dtype_of(t):
+        return torch.float16 if t.dtype == torch.float16 else torch.float32
 
     def save(self, path: str):
         """Persist the label bank and every query embedding seen so far (plain tensors + strings), so later
@@ -52,7 +62,8 @@ class TextSimilarity:
         self = cls.__new__(cls)
         self.device = torch.device(device)
         self.labels = list(blob["labels"])
-        self.bank = blob["bank"].to(torch.float16).to(self.device).contiguous()
+        self.dtype = cls._dtype_of(blob["bank"])
+        self.bank = blob["bank"].to(self.dtype).to(self.device).contiguous()
         self.index = {lab: i for i, lab in enumerate(self.labels)}
         self._cache = {}
         self._query_emb = dict(blob.get("queries", {}))
@@ -66,20 +77,13 @@ class TextSimilarity:
         self.encode_text = enc
         return self
 
-    @staticmethod
-    def _pad(x):
-        d = x.shape[1]
-        pad = (-d) % 32
-        return torch.nn.functional.pad(x, (0, pad)) if pad else x
-
     def query(self, text: str) -> np.ndarray:
-        """float32 [n_labels]: cosine of `text` against every bank label."""
+        """float32 [n_labels]: cosine of `text` against every bank label (values of the bank's dtype)."""
         if text not in self._cache:
             with torch.no_grad():
-                emb = self.encode_text(text).reshape(1, -1).to(torch.float16)
+                emb = self.encode_text(text).reshape(1, -1).to(self.dtype)
                 self._query_emb[text] = emb.cpu()
-                q = self._pad(emb).to(self.device).contiguous()
-            self._cache[text] = _lib.cosine_gemm_f16(q, self.bank)[0].cpu().numpy()
+            self._cache[text] = _lib.cosine_rows(emb.to(self.device).contiguous(), self.bank)[0].cpu().numpy()
         return self._cache[text]
 
     def similarities(self, text: str, labels: Sequence[str]) -> List[float]:

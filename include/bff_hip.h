@@ -32,7 +32,7 @@ extern "C" {
 #define BFF_E_ARG (-1)      /* null pointer / negative size / unsupported parameter */
 #define BFF_E_LIMIT (-2)    /* size beyond what a kernel supports (documented per call) */
 
-#define BFF_ABI_VERSION 2
+#define BFF_ABI_VERSION 3
 
 int bff_abi_version(void);
 const char *bff_last_error(void);
@@ -335,6 +335,14 @@ int bff_argsort_i64(const int64_t *keys, int64_t *keys_scratch, int32_t *order_o
  * dim % 32 == 0, cos: float32 [na][nb]. */
 int bff_cosine_gemm_f16(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim,
                         float *cos, void *stream);
+
+/* a21 -- the per-class text cosines in the dtype of the embeddings: cos[i][j] with every tensor op of
+ *   (e1 @ e2.T) / (e1.norm() * e2.norm().T)  (compute_clip_similarity R:109-114) rounded to that dtype, so that
+ * the SET of similarities the class threshold is taken from (R:321-324) ties exactly where the reference's
+ * does (fp16 CLIP on a GPU: multiples of 2^-11).  dtype 0: a, b float32; dtype 1: a, b float16; cos float32
+ * (holding float16 values for dtype 1); float64 accumulation; any dim. */
+int bff_cosine_rows(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim, int32_t dtype,
+                    float *cos, void *stream);
 
 #ifdef __cplusplus
 }

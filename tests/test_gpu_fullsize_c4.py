@@ -1,0 +1,141 @@
+"""GPU parity at BASELINE config 4's full size (1 M points, 600 views @968x1296, 64 masks/view, Ins = 38 400:
+the 64-bit mask-word path and the largest Gram) through size-independent properties, plus the oracle on a
+frame subset at full N / HxW / M.  Same pattern as tests/test_gpu_fullsize.py (config 2).  The complete CPU
+oracle at this size would take tens of minutes and is not part of the suite; set BFF_SKIP_C4=1 to skip the file."""
+import copy
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import projection_ref as pref
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("BFF_SKIP_C4") == "1", reason="config 4 skipped on request")]
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def c4():
+    from beyond_fixed_forms_amd import _lib
+    from beyond_fixed_forms_amd.config import Config
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    from beyond_fixed_forms_amd.synthetic import make_scene
+    _lib.load()
+    scene = make_scene("c4", seed=0, device=DEV)
+    cfg = Config.with_defaults(width_2d=scene.width, height_2d=scene.height)
+    return scene, cfg, prepare_scene(scene, cfg, device=DEV)
+
+
+def bits(rows, n):
+    return np.unpackbits(rows.cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[:, :n].astype(bool)
+
+
+def test_c4_checksums_layout_and_sweeps(c4):
+    """(a) every set instance bit is one vote: sum of row popcounts == sum of masked_count; (b) Morton-sorted
+    layout == the caller's point order; (c) one fused sweep == a mask sweep + a separate viewed sweep."""
+    from beyond_fixed_forms_amd import _lib
+    from beyond_fixed_forms_amd.projection import run_projection
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    scene, cfg, ds = c4
+    assert ds.word_bits == 64 and ds.n_rows == 38_400 and ds.n_points == 1_000_000
+    res = run_projection(ds, cfg, debug_out=True)
+    raw, masked, viewed = res.debug["raw_rows"], res.debug["masked_counts_raw"], res.debug["viewed_counts"]
+    assert int(_lib.popcount_rows(raw).sum().item()) == int(masked.sum().item()) > 10 ** 7
+    assert int(viewed.max().item()) <= ds.n_viewed and int(masked.max().item()) <= ds.n_rows
+    groups, out_rows, out_conf = list(res.groups), res.rows.clone(), res.conf.clone()
+    del res
+    ds_plain = prepare_scene(scene, cfg, device=DEV, sort_points=False)
+    res2 = run_projection(ds_plain, cfg, debug_out=True)
+    assert torch.equal(res2.debug["raw_rows"], raw) and torch.equal(res2.debug["masked_counts_raw"], masked)
+    assert torch.equal(res2.debug["viewed_counts"], viewed)
+    assert list(res2.groups) == groups and torch.equal(res2.rows, out_rows) and torch.equal(res2.conf, out_conf)
+    del res2
+    # separate sweeps on the unsorted layout, full images (no segment bitmap, no chunk flags)
+    n = ds_plain.n_points
+    hw = ds_plain.height * ds_plain.width
+    mb = torch.empty((ds_plain.n_mask_frames, hw), dtype=torch.int64, device=DEV)
+    _lib.rle_to_maskbits(ds_plain.run_start, ds_plain.run_end, ds_plain.mask_run_offs, ds_plain.view_mask_offs,
+                         ds_plain.n_mask_frames, hw, 64, mb)
+    rows_a = torch.zeros_like(raw)
+    m_a = torch.zeros(n, dtype=torch.int32, device=DEV)
+    v_a = torch.zeros(n, dtype=torch.int32, device=DEV)
+    zero_flags = torch.zeros_like(ds_plain.frame_flags)
+    _lib.project_views(ds_plain.xyz, n, ds_plain.inv_pose, ds_plain.cam_intr, ds_plain.depth, ds_plain.depth_index,
+                       ds_plain.height, ds_plain.width, 0.08, mb, 64, ds_plain.frame_mask, ds_plain.frame_rowbase,
+                       ds_plain.frame_nmask, zero_flags, rows_a, m_a, None)
+    _lib.project_views(ds_plain.xyz, n, ds_plain.inv_pose, ds_plain.cam_intr, ds_plain.depth, ds_plain.depth_index,
+                       ds_plain.height, ds_plain.width, 0.08, None, 64, ds_plain.frame_mask, ds_plain.frame_rowbase,
+                       ds_plain.frame_nmask, torch.ones_like(zero_flags), None, None, v_a)
+    assert torch.equal(rows_a, raw) and torch.equal(m_a, masked) and torch.equal(v_a, viewed)
+
+
+def test_c4_components_two_formulations_agree(c4):
+    """Union-find tile pass (production) == adjacency matrix + label propagation (cross-check) at Ins = 38 400."""
+    from beyond_fixed_forms_amd import _lib
+    from beyond_fixed_forms_amd.projection import groups_from_labels, run_projection
+    scene, cfg, ds = c4
+    res = run_projection(ds, cfg, debug_out=True)
+    rows = res.debug["raw_rows"]
+    area, _mw, cmask, hist, sig = _lib.row_stats(rows)
+    order = _lib.argsort_i64(sig, _lib.SIGNATURE_BITS)
+    comp = _lib.merge_components(rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist).cpu().numpy()
+    # cross-check formulation: every pair of rows that share a chunk gets its exact intersection (no histogram
+    # bounds, no forest), then min-label propagation over the adjacency bit matrix
+    adj = _lib.merge_adjacency(rows, area, ds.label_id, cfg.iou_thres, order=order, chunk_mask=cmask)
+    lab_pos = _lib.components(adj).cpu().numpy()                 # labels over positions in `order`
+    o = order.cpu().numpy()
+    lab = np.empty_like(lab_pos)
+    lab[o] = o[lab_pos]                                          # component named by one of its rows
+    self_loop = area.cpu().numpy() > 0
+    g_uf, g_adj = groups_from_labels(comp, self_loop, 2), groups_from_labels(lab, self_loop, 2)
+    assert g_uf == g_adj == list(res.groups) and len(g_uf) > 0
+
+
+def test_c4_decode_checksum(c4):
+    """64-bit mask words: per mask, the number of pixels with its bit set == the total run length of its RLE;
+    no bit beyond the frame's mask count is ever set."""
+    from beyond_fixed_forms_amd import _lib
+    scene, cfg, ds = c4
+    hw = ds.height * ds.width
+    nv = 4
+    mb = torch.empty((nv, hw), dtype=torch.int64, device=DEV)
+    _lib.rle_to_maskbits(ds.run_start, ds.run_end, ds.mask_run_offs, ds.view_mask_offs, nv, hw, 64, mb)
+    run_len = (ds.run_end - ds.run_start).cpu().numpy().astype(np.int64)
+    offs = ds.mask_run_offs.cpu().numpy()
+    voffs = ds.view_mask_offs.cpu().numpy()
+    for v in range(nv):
+        img = mb[v].cpu().numpy().view(np.uint64)
+        m = int(voffs[v + 1] - voffs[v])
+        assert m == 64
+        for b in range(m):
+            g = voffs[v] + b
+            assert int(((img >> np.uint64(b)) & np.uint64(1)).sum()) == int(run_len[offs[g]:offs[g + 1]].sum()), (v, b)
+
+
+def test_c4_oracle_on_a_frame_subset_at_full_size(c4):
+    """Oracle (CPU) on 3 of the 600 frames at full N / HxW / M = 64: raw instance rows, both vote counters,
+    merge groups and the stage-2 result of the HIP path are bit-identical."""
+    from beyond_fixed_forms_amd.projection import run_projection
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    scene, cfg, _ = c4
+    sub = copy.copy(scene)
+    sub.mask_2d = [dict(f) for f in scene.mask_2d[200:203]]
+    keep = {int(f["frame_id"][:-4]) for f in sub.mask_2d}
+    sub.color_files = [f"{i}.jpg" for i in sorted(keep)]
+    cfg1 = type(cfg)(cfg); cfg1["downsample_ratio"] = 1
+    torch.set_num_threads(16)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp, dbg = pref.project_scene_ref(sub, cfg1, return_debug=True)
+    res = run_projection(prepare_scene(sub, cfg1, device=DEV), cfg1, debug_out=True)
+    n = scene.points.shape[0]
+    assert np.array_equal(bits(res.debug["raw_rows"], n), dbg["raw_ins"].numpy())
+    assert np.array_equal(res.debug["masked_counts_raw"].cpu().numpy(), dbg["masked_counts_raw"].numpy().astype(np.int32))
+    assert np.array_equal(res.debug["viewed_counts"].cpu().numpy(), dbg["viewed_counts"].numpy().astype(np.int32))
+    assert list(res.groups) == dbg["groups"]
+    got = res.to_dict()
+    assert tuple(got["ins"].shape) == tuple(exp["ins"].shape) and torch.equal(got["ins"].cpu(), exp["ins"])
+    assert torch.equal(got["conf"].cpu(), exp["conf"])

@@ -544,3 +544,130 @@ def test_library_sorts(lib, n):
     small = torch.randint(0, 1 << 30, (n,), generator=g, dtype=torch.int64) >> torch.randint(0, 30, (n,), generator=g)
     order = lib.argsort_i64(small.to(DEV), 30).cpu().long()           # 30-bit keys: fewer radix passes
     assert torch.equal(order, torch.argsort(small, stable=True))
+
+
+# ------------------------------------------------------------------ golden aggregation cases on the device
+AGG_CASES = ["random_f16", "random_f32", "chain_empty_single", "borderline", "nothing_merges", "min_members_1"]
+
+
+@pytest.mark.parametrize("case", AGG_CASES)
+def test_aggregation_golden_on_device(lib, case):
+    """Every aggregate() fixture the reference's helpers produced (tests/golden/agg_helpers.npz: IoU exactly 1/5
+    which is NOT > f32(0.2), a chain a~b~c, empty rows -> NaN IoU -> `[]`, singletons, a second label,
+    min_aggragated_masks = 1, nothing merging) through the device path: merge matrix, components, kept groups,
+    OR of the members, sequential confidence mean in the confidence dtype, label of the first member."""
+    from beyond_fixed_forms_amd.projection import component_csr, groups_from_labels
+    z = Z("agg_helpers.npz")
+    g = lambda k: z[f"{case}.{k}"]
+    n = int(g("n"))
+    d = gio.unpack_bool_rows(g("ins"), n)
+    labels = [str(s) for s in g("labels")]
+    conf = torch.from_numpy(g("conf").copy())
+    if str(g("conf_dtype")) == "torch.float16":
+        conf = conf.half()
+    min_members = int(g("min_members"))
+    rows = pack_np(d)
+    ids = {}
+    lid = torch.tensor([ids.setdefault(s, len(ids)) for s in labels], dtype=torch.int32, device=DEV)
+    area, _mw, cmask, hist, sig = lib.row_stats(rows)
+    assert np.array_equal(area.cpu().numpy(), d.sum(1))
+    # a10/a11: same_label & (iou > f32(0.2)), bit for bit the reference's merge matrix
+    adj, inter = lib.merge_adjacency(rows, area, lid, 0.2, want_inter=True)
+    assert np.array_equal(unpack(adj, len(labels)), g("merge"))
+    a = area.cpu().numpy().astype(np.float32)
+    fi = inter.cpu().numpy().astype(np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        iou = fi / (a[:, None] + a[None, :] - fi)                        # float32, the expression of P:149-166
+    assert np.array_equal(iou.view(np.uint32), g("iou_bits"))
+    # a12: components (production union-find, three row orders) == find_unconnected_subgraphs_tensor
+    self_loop = np.diag(g("merge"))
+    r = len(labels)
+    rng = np.random.default_rng(3)
+    for order in (torch.arange(r, dtype=torch.int32, device=DEV), lib.argsort_i64(sig, lib.SIGNATURE_BITS),
+                  torch.from_numpy(rng.permutation(r).astype(np.int32)).to(DEV)):
+        comp = lib.merge_components(rows, area, lid, 0.2, order, cmask, hist).cpu().numpy()
+        assert groups_from_labels(comp, self_loop) == gio.loads_groups(g("components"))
+        assert groups_from_labels(comp, self_loop, min_members) == gio.loads_groups(g("groups"))
+    assert groups_from_labels(lib.components(adj).cpu().numpy(), self_loop) == gio.loads_groups(g("components"))
+    # a13: merge_masks on the kept groups
+    offs, members, sizes, _ = component_csr(comp, self_loop, min_members)
+    exp_kind = str(g("agg.kind"))
+    if len(sizes) == 0:
+        assert exp_kind != "rows"
+        return
+    t32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(DEV)
+    out, mean = lib.or_reduce_groups(rows, t32(offs), t32(members), int(sizes.max()), conf.to(DEV))
+    assert exp_kind == "rows"
+    assert np.array_equal(np.packbits(unpack(out, n), axis=-1, bitorder="little"), g("agg.ins_packed"))
+    assert str(mean.dtype) == str(g("agg.conf_dtype"))
+    assert np.array_equal(mean.cpu().float().numpy(), g("agg.conf"))
+    assert [labels[i] for i in members[offs[:-1]]] == [str(s) for s in g("agg.final_class")]
+
+
+def test_cosine_golden_on_device(lib):
+    """compute_clip_similarity (R:93-115) fixtures: the embeddings of tests/golden/refine_helpers.npz through
+    (a) bff_cosine_rows, which rounds every tensor op to the embedding dtype like the reference (float16: the
+    values are multiples of 2^-11, identical texts give 0.99951172, equal rows tie exactly), and (b) the MFMA
+    GEMM bff_cosine_gemm_f16 (float32 normalisation; tolerance of north_star: 1e-4)."""
+    z = Z("refine_helpers.npz")
+    e32 = torch.from_numpy(z["clip.emb_f32"][:, 0, :].copy())
+    e16 = torch.from_numpy(z["clip.emb_f16"][:, 0, :].copy()).half()
+    got32 = lib.cosine_rows(e32.to(DEV), e32.to(DEV)).cpu().numpy().astype(np.float64)
+    assert np.abs(got32 - z["clip.sims_f32"]).max() <= 1e-4              # north_star's tolerance
+    assert np.abs(got32 - z["clip.sims_f32"]).max() <= 2e-7              # observed: the last ulp of a float32 dot
+    got16 = lib.cosine_rows(e16.to(DEV), e16.to(DEV)).cpu().numpy().astype(np.float64)
+    assert np.array_equal(got16, got16.astype(np.float16).astype(np.float64))       # float16 values
+    assert np.abs(got16 - z["clip.sims_f16"]).max() <= 2.0 ** -11        # one float16 ulp below 1.0
+    assert got16[0, 0] == z["clip.sims_f16"][0, 0] == 0.99951171875      # the reference's self-similarity in fp16
+    assert got16[0, 5] == got16[0, 0] and np.array_equal(got16[5], got16[0])        # equal embeddings tie
+    n_same = int((got16 == z["clip.sims_f16"]).sum())
+    assert n_same >= 34, n_same                                          # all but rounding-boundary cases identical
+    # MFMA GEMM on the same float16 embeddings (dim 64 = 2 k-steps): float32 normalisation
+    pad = lambda x: x.to(DEV).contiguous()
+    gemm = lib.cosine_gemm_f16(pad(e16), pad(e16)).cpu().numpy().astype(np.float64)
+    e = e16.double()
+    exact = ((e @ e.T) / (e.norm(dim=1, keepdim=True) * e.norm(dim=1, keepdim=True).T)).numpy()
+    assert np.abs(gemm - exact).max() <= 1e-4
+    assert np.abs(gemm - z["clip.sims_f16"]).max() <= 2.0 ** -11 + 1e-4  # the golden values are rounded to float16
+    # 9000 x 768 against a 200-label bank (BASELINE config 5 at full size), vs float64
+    gen = torch.Generator().manual_seed(5)
+    a = torch.randn(9000, 768, generator=gen).half()
+    b = torch.randn(200, 768, generator=gen).half()
+    big = lib.cosine_gemm_f16(a.to(DEV), b.to(DEV)).cpu().double()
+    ad, bd = a.double(), b.double()
+    ref = (ad @ bd.T) / (ad.norm(dim=1, keepdim=True) * bd.norm(dim=1, keepdim=True).T)
+    assert (big - ref).abs().max().item() <= 1e-4
+    # and bff_cosine_rows against the same float64 values, on both dtypes
+    sub = lib.cosine_rows(a[:50].to(DEV), b.to(DEV)).cpu().double()
+    assert (sub - ref[:50]).abs().max().item() <= 2.0 ** -11
+    sub32 = lib.cosine_rows(a[:50].float().to(DEV), b.float().to(DEV)).cpu().double()
+    assert (sub32 - ref[:50]).abs().max().item() <= 2e-7
+
+
+@pytest.mark.parametrize("thr", [-1.0, -0.5, 0.0])
+def test_components_negative_threshold_with_empty_tiles(lib, thr):
+    """iou_thres < 0: an empty row (IoU 0 with any non-empty row of its label, NaN with another empty row) joins
+    the component of its label.  150 of 300 rows are empty, so whole 64-row tiles are empty in the sorted order --
+    tiles the tile-pair filter may only drop when 0 > thr is false."""
+    from beyond_fixed_forms_amd.projection import groups_from_labels
+    rng = np.random.default_rng(23)
+    r, n = 300, 20_000
+    d = np.zeros((r, n), bool)
+    for i in range(150):
+        c = int(rng.integers(0, 5)) * 4000 + int(rng.integers(0, 300))
+        d[i, c: c + int(rng.integers(50, 2000))] = True
+    d = d[rng.permutation(r)]
+    labels = rng.integers(0, 2, r)
+    t = torch.from_numpy(d)
+    iou = pref.pairwise_iou(t)
+    merge = ((torch.from_numpy(labels)[:, None] == torch.from_numpy(labels)[None, :]) & (iou > thr)).numpy()
+    exp = pref.connected_groups(torch.from_numpy(merge).float())
+    rows = pack_np(d)
+    lid = torch.tensor(labels, dtype=torch.int32, device=DEV)
+    area, _mw, cmask, hist, sig = lib.row_stats(rows)
+    self_loop = np.diag(merge)
+    for order in (lib.argsort_i64(sig, lib.SIGNATURE_BITS), torch.arange(r, dtype=torch.int32, device=DEV)):
+        comp = lib.merge_components(rows, area, lid, thr, order, cmask, hist).cpu().numpy()
+        assert groups_from_labels(comp, self_loop) == exp
+    if thr < 0:
+        assert any(len(g) > 100 for g in exp)                    # the empty rows did join

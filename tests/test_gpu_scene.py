@@ -352,3 +352,68 @@ def test_run_class_two_ranks_equals_single_process(api):
         n = e["ins"].shape[1]
         dense = np.unpackbits(rows.numpy().view(np.uint8), axis=-1, bitorder="little")[:, :n].astype(bool)
         assert np.array_equal(dense, e["ins"].numpy()) and torch.equal(conf, e["conf"]) and cls == e["final_class"]
+
+
+@pytest.mark.parametrize("enc_dtype", [torch.float32, torch.float16])
+def test_similarity_set_near_ties(api, enc_dtype):
+    """The class threshold is sorted(set(similarities))[int(n * 0.2)] (R:321-324): it depends on which values TIE.
+    Labels are crafted whose cosines with the query differ by 2e-6 .. 3e-4: distinct in float32, partly collapsing
+    in float16 (CLIP on a GPU emits fp16; cosines are then multiples of 2^-11 .. 2^-13).  The product computes the
+    cosines in the encoder's dtype with the reference's op-by-op rounding (bff_cosine_rows), so the SET -- its
+    size, its order, hence the index picked and the masks dropped -- equals the oracle's on the same embeddings."""
+    _, refinement = api
+    from beyond_fixed_forms_amd.labels import SCANNET200_LABELS
+    from oracle.rle_ref import rle_encode_batch_ref
+    n, k, d = 4000, 12, 64
+    gen = torch.Generator().manual_seed(41)
+    q = torch.randn(d, generator=gen, dtype=torch.float64)
+    q /= q.norm()
+    target = [0.30, 0.30 + 2e-6, 0.30 + 6e-6, 0.3001, 0.3003, 0.31, 0.31 + 3e-6, 0.35, 0.3502, 0.40, 0.41, 0.41 + 5e-5]
+    bank = torch.randn(len(SCANNET200_LABELS), d, generator=gen, dtype=torch.float64)
+    labs = [SCANNET200_LABELS[5 + 3 * i] for i in range(k)]
+    for c, lab in zip(target, labs):
+        r = torch.randn(d, generator=gen, dtype=torch.float64)
+        r -= (r @ q) * q
+        r /= r.norm()
+        bank[SCANNET200_LABELS.index(lab)] = (c * q + (1 - c * c) ** 0.5 * r) * 3.7
+    bank[SCANNET200_LABELS.index("table")] = q * 2.5
+    bank = bank.to(enc_dtype)
+    index = {lab: i for i, lab in enumerate(SCANNET200_LABELS)}
+    enc = bank_encoder(bank, index)
+    # stage 1: k disjoint masks with the crafted labels (+ one with the query label); stage 2: one mask per
+    # stage-1 mask with IoU 0.9 > refiment_iou_thres, so every matched mask is kept or dropped by its similarity
+    s1 = np.zeros((k + 1, n), bool)
+    s2 = np.zeros((k, n), bool)
+    for i in range(k):
+        s1[i, 300 * i: 300 * i + 200] = True
+        s2[i, 300 * i + 10: 300 * i + 200] = True
+    s1[k, 3800:3900] = True
+    stage1 = {"ins": rle_encode_batch_ref(torch.from_numpy(s1)), "conf": torch.ones(k + 1),
+              "final_class": [SCANNET200_LABELS.index(l) for l in labs] + [SCANNET200_LABELS.index("table")]}
+    conf = torch.linspace(0.2, 0.5, k).to(torch.float16)
+    cfg = cfg_for(type("S", (), {"width": 8, "height": 8}))
+    # three scenes of the class see different subsets of the labels; the set is pooled over all of them
+    scenes_p, scenes_o = [], []
+    for s, sel in enumerate(([0, 1, 2, 3, 9], [4, 5, 6, 7, 10], [1, 6, 8, 11, 2])):
+        st2 = {"ins": torch.from_numpy(s2[sel]), "conf": conf[sel].clone(), "final_class": ["table"] * len(sel)}
+        scenes_p.append((f"s{s}_00", stage1, st2))
+        scenes_o.append((f"s{s}_00", stage1, {kk: (v.clone() if torch.is_tensor(v) else list(v)) for kk, v in st2.items()}))
+    fexp, odbg = rref.refine_class_ref(scenes_o, cfg, "table", enc, return_debug=True)
+    sim = refinement.TextSimilarity(enc, DEV)
+    assert sim.dtype == enc_dtype
+    fin, dbg = refinement.refine_class(scenes_p, cfg, "table", sim, DEV, return_debug=True)
+    got_set = sorted(set(v for st in dbg["states"] for v in st.sims))
+    exp_set = odbg["sim_unique"]
+    assert len(got_set) == len(exp_set)                                   # the same values tie
+    if enc_dtype == torch.float16:
+        assert len(exp_set) < k                                           # ... and in fp16 some do
+        assert got_set == exp_set and dbg["sim_thres"] == odbg["sim_thres"]
+    else:
+        assert len(exp_set) == k                                          # 2e-6 apart: all distinct in float32
+        assert np.abs(np.array(got_set) - np.array(exp_set)).max() <= 2e-7
+        assert abs(dbg["sim_thres"] - odbg["sim_thres"]) <= 2e-7
+    # same order of the labels along the sorted set -> same index -> same masks dropped
+    for (sid, _, _) in scenes_p:
+        same(fin[sid].to_dict(), fexp[sid])
+    dropped = sum(5 + 1 - fexp[sid]["ins"].shape[0] for sid, _, _ in scenes_p)     # 5 matched + 1 other per scene
+    assert dropped > 0                                                    # the threshold did bite

@@ -183,3 +183,40 @@ def test_sim_threshold_semantics():
     assert sim_threshold([[0.5, 0.1], [0.9, 0.3, 0.7]], 0.2) == 0.3            # 5 values -> index 1
     with pytest.raises(IndexError):
         sim_threshold([[]], 0.2)
+
+
+def test_bilinear_resize_hand_derived_fixture():
+    """cv2.resize(INTER_LINEAR) restatement against a fixture derived by hand from the definition (not from the
+    code): 2x3 -> 5x7.  Source x of destination column dx is (dx + 0.5) * 3/7 - 0.5 = -2/7, 1/7, 4/7, 1, 10/7,
+    13/7, 16/7: column 0 lies left of the image (copies column 0), column 6 has floor 2 = last column (copies it),
+    the others blend columns (0,1) or (1,2) with fractions 1/7, 4/7, 0, 3/7, 6/7.  Source y of row dy is
+    (dy + 0.5) * 2/5 - 0.5 = -0.3, 0.1, 0.5, 0.9, 1.3: rows 0 and 4 clamp both taps onto one row, so they equal
+    that row; rows 1..3 blend rows (0,1) with 0.1, 0.5, 0.9.  cv2 itself is absent here: parity with it stays
+    unpinned, this pins the restatement to the published definition."""
+    from beyond_fixed_forms_amd import io
+    src = np.array([[10.0, 20.0, 40.0], [110.0, 220.0, 440.0]], np.float32)
+    got = io.resize_bilinear_f32(src, 7, 5)
+    assert got.shape == (5, 7) and got.dtype == np.float32
+    fx = [None, 1 / 7, 4 / 7, 0.0, 3 / 7, 6 / 7, None]
+    left = [0, 0, 0, 1, 1, 1, 2]
+    hrow = lambda r: np.array([r[left[d]] if fx[d] is None else r[left[d]] * (1 - fx[d]) + r[left[d] + 1] * fx[d]
+                               for d in range(7)])
+    h0, h1 = hrow(src[0].astype(np.float64)), hrow(src[1].astype(np.float64))
+    fy = [None, 0.1, 0.5, 0.9, None]
+    exp = np.stack([h0, h0 * 0.9 + h1 * 0.1, h0 * 0.5 + h1 * 0.5, h0 * 0.1 + h1 * 0.9, h1])
+    assert np.abs(got.astype(np.float64) - exp).max() <= 440 * 2.0 ** -21          # float32 arithmetic, few ulps
+    assert np.array_equal(got[:, 0], got[:, 0]) and got[0, 0] == 10.0 and got[4, 6] == 440.0     # corners are copies
+    assert np.array_equal(got[0, [0, 3, 6]], src[0]) and np.array_equal(got[4, [0, 3, 6]], src[1])
+    # tap tables: the x border taps have fraction exactly 0, the y fraction is kept when the rows clamp
+    x0, x1, ax, y0, y1, ay = io.bilinear_taps(2, 3, 5, 7)
+    assert x0.tolist() == [0, 0, 0, 1, 1, 1, 2] and ax[0] == 0 and ax[6] == 0 and ax[3] == 0
+    assert y0.tolist() == [0, 0, 0, 0, 1] and y1.tolist() == [0, 1, 1, 1, 1]
+    assert abs(float(ay[0]) - 0.7) < 1e-6 and abs(float(ay[4]) - 0.3) < 1e-6
+    # the fraction is float32(source coordinate) - floor, as cv2 computes it (not the float64 fraction cast down)
+    big = io.bilinear_taps(480, 640, 968, 1296)
+    f = np.float32((np.float64(1295) + 0.5) * (1.0 / (1296 / 640)) - 0.5)
+    assert big[2][1295] == 0.0 and big[0][1295] == 639
+    f = np.float32((np.float64(1000) + 0.5) * (1.0 / (1296 / 640)) - 0.5)
+    assert big[2][1000] == np.float32(f - np.float32(np.floor(f)))
+    # identity
+    assert np.array_equal(io.resize_bilinear_f32(src, 3, 2), src)

@@ -120,7 +120,14 @@ def test_refinement_helpers():
         emb = torch.from_numpy(z[f"clip.emb_{tag}"]).to(dt)
         sims = np.array([[rref.text_cosine(lambda t: emb[int(t[1:])], f"a{a}", f"b{b}") for b in range(6)]
                          for a in range(6)])
-        assert np.array_equal(sims, z[f"clip.sims_{tag}"])
+        # The golden values came out of the reference's compute_clip_similarity on the build container's CPU.  A
+        # float32 / float16 BLAS dot sums in a host-dependent order (the EPYC of the GPU box differs from the
+        # build container in the last ulp), so bit equality across machines is not defined for this quantity;
+        # north_star's tolerance for cosines is 1e-4.  Asserted: that tolerance for float32 (observed: 1 ulp),
+        # one float16 ulp (2^-11 below 1.0) for the float16 expression, whose every op rounds to float16.
+        tol = 1e-4 if tag == "f32" else 2.0 ** -11
+        assert np.abs(sims - z[f"clip.sims_{tag}"]).max() <= tol
+        assert np.abs(sims - z[f"clip.sims_{tag}"]).max() <= (4e-7 if tag == "f32" else tol)     # in fact: an ulp
     with open(os.path.join(gio.GOLDEN_DIR, "scannet200_labels.json")) as f:
         labels = json.load(f)
     assert labels == rref.SCANNET200
