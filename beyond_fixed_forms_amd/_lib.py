@@ -22,7 +22,8 @@ _P, _I, _L, _D, _F = c_void_p, c_int32, c_int64, c_double, c_float
 # name -> argument ctypes (every entry point returns int); mirrors include/bff_hip.h one to one
 SIGNATURES = {
     "bff_rle_to_maskbits": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P],
-    "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P],
+    "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P],
+    "bff_point_tile_bounds": [_P, _L, _L, _P, _P],
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
     "bff_row_stats": [_P, _I, _L, _P, _P, _P, _I, _P, _P, _P],
@@ -55,6 +56,8 @@ SIGNATURES = {
 }
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
          "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
+         "bff_point_tile_size": (c_int32, []), "bff_merge_scratch_words": (c_int64, [c_int32]),
+         "bff_profile_next_merge": (c_int32, [_P, _P]),
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
          "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
          "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}
@@ -156,7 +159,7 @@ def rle_to_maskbits(run_start, run_end, mask_run_offs, view_mask_offs, n_views, 
 
 def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, height, width, depth_thresh,
                   maskbits, word_bits, frame_mask, frame_rowbase, frame_nmask, frame_flags,
-                  rows, masked_count, viewed_count, segmap=None, chunk_mask=None):
+                  rows, masked_count, viewed_count, segmap=None, chunk_mask=None, tile_bounds=None):
     k = (c_double * 9)(*[float(v) for v in cam_intr.reshape(-1)])
     n_frames = inv_pose.shape[0]
     nw = (n_points + 63) // 64
@@ -165,7 +168,15 @@ def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, hei
          float(depth_thresh), _ptr(maskbits), _ptr(segmap, i32), word_bits, _ptr(frame_mask, i32), _ptr(frame_rowbase, i32),
          _ptr(frame_nmask, i32), _ptr(frame_flags, i32), _ptr(rows, i64),
          0 if rows is None else rows.shape[0], nw, _ptr(chunk_mask, i64), _ptr(masked_count, i32),
-         _ptr(viewed_count, i32))
+         _ptr(viewed_count, i32), _ptr(tile_bounds, f64))
+
+
+def point_tile_bounds(xyz_soa, n_points):
+    """float64 [tiles][6] bounding boxes of the sweep's point tiles (frustum culling table of project_views)."""
+    tile = load().bff_point_tile_size()
+    out = torch.empty((max(1, (n_points + tile - 1) // tile), 6), dtype=f64, device=xyz_soa.device)
+    call("bff_point_tile_bounds", _ptr(xyz_soa, f64), n_points, xyz_soa.shape[1], _ptr(out))
+    return out
 
 
 def popcount_rows(rows, idx=None):
@@ -253,7 +264,7 @@ def merge_components(rows, area, label_id, iou_thres, order, chunk_mask, hist, d
     if init:
         parent = torch.empty(n, dtype=i32, device=rows.device)
     comp = torch.empty(n, dtype=i32, device=rows.device)
-    hist_sorted = torch.empty(64 * 64 * nt + 65 * nt + 1 + nt * (nt + 1) // 2, dtype=i32, device=rows.device)  # scratch, see bff_hip.h
+    hist_sorted = torch.empty(int(load().bff_merge_scratch_words(n)), dtype=i32, device=rows.device)  # scratch, see bff_hip.h
 
     def run(ordr, init_parent, out):
         call("bff_merge_components", _ptr(rows, i64), n, rows.shape[1], _ptr(ordr, i32), ordr.shape[0],

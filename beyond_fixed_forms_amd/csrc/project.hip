@@ -37,7 +37,8 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
     const int32_t *__restrict__ frame_rowbase, const int32_t *__restrict__ frame_nmask,
     const int32_t *__restrict__ frame_flags,
     uint64_t *__restrict__ rows, int64_t nw, uint64_t *__restrict__ chunk_mask, int mw,
-    int32_t *__restrict__ masked_count, int32_t *__restrict__ viewed_count)
+    int32_t *__restrict__ masked_count, int32_t *__restrict__ viewed_count,
+    const double *__restrict__ tile_bounds)
 {
     // per wave: [bit][kPPT words] transposition buffer for the wave's sector of the frame's rows
     __shared__ uint64_t stage_all[kBlock / kWave][sizeof(WordT) * 8][kPPT];
@@ -65,7 +66,48 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
     const int f0 = blockIdx.y * frames_per_block;
     const int f1 = min(n_frames, f0 + frames_per_block);
     const double dW = (double)W, dH = (double)H;
+    // Frustum culling of the wave's 256 points against the <= 8 frames of the tile, all at once: lane = 8 * frame
+    // + corner of the points' bounding box.  A point can only be visible if its pixel is in bounds, i.e. (exact
+    // arithmetic) it lies in the double cone  {L_i >= 0 for all i, c_z > 0}  u  {L_i <= 0 for all i, c_z < 0}  with
+    //   L_1 = p_0 + (1/2 + m) c_z,  L_2 = (W - 1/2 + m) c_z - p_0,  L_3 = p_1 + (1/2 + m) c_z,  L_4 = (H - 1/2 + m) c_z - p_1
+    // (the two image borders in u and in v, widened by m = 0.01 pixel; the reference has no z > 0 test, hence both
+    // cones).  Each L_i is an affine function of the world point, so its value anywhere in the box is a convex
+    // combination of the 8 corner values: if some L_i < -delta at every corner the box misses the front cone, if
+    // some L_j > +delta at every corner it misses the back cone; a frame is skipped only when both hold.  delta =
+    // 1e-6 and m exceed the float64 rounding of these forms (~1e-11) by orders of magnitude; NaN / inf corner
+    // values compare false and keep the frame.  Exact: a skipped frame has no in-bounds point in this wave.
+    uint64_t culled = 0;                                   // bit 8 k set: frame f0 + k cannot see this wave's points
+    if (tile_bounds) {
+        const double *bb = tile_bounds + 6 * (word0 / kPPT);
+        const int corner = lane & 7, fk = lane >> 3;
+        const double bx = (corner & 1) ? bb[3] : bb[0], by = (corner & 2) ? bb[4] : bb[1], bz = (corner & 4) ? bb[5] : bb[2];
+        double l1 = 0.0, l2 = 0.0, l3 = 0.0, l4 = 0.0;
+        if (f0 + fk < f1) {
+            const double *P = inv_pose + 16 * (int64_t)(f0 + fk);
+            const double cx = fma(P[2], bz, fma(P[1], by, P[0] * bx)) + P[3];
+            const double cy = fma(P[6], bz, fma(P[5], by, P[4] * bx)) + P[7];
+            const double cz = fma(P[10], bz, fma(P[9], by, P[8] * bx)) + P[11];
+            const double p0 = fma(K.k[2], cz, fma(K.k[1], cy, K.k[0] * cx));
+            const double p1 = fma(K.k[5], cz, fma(K.k[4], cy, K.k[3] * cx));
+            constexpr double m = 0.01;
+            l1 = fma(0.5 + m, cz, p0);
+            l2 = fma(dW - 0.5 + m, cz, -p0);
+            l3 = fma(0.5 + m, cz, p1);
+            l4 = fma(dH - 0.5 + m, cz, -p1);
+        }
+        constexpr double delta = 1e-6;
+        auto all8 = [](uint64_t b) {                       // bit 8 k of the result = all 8 bits of byte k set
+            b &= b >> 1; b &= b >> 2; b &= b >> 4;
+            return b & 0x0101010101010101ull;
+        };
+        const uint64_t neg = all8(__ballot(l1 < -delta)) | all8(__ballot(l2 < -delta)) |
+                             all8(__ballot(l3 < -delta)) | all8(__ballot(l4 < -delta));
+        const uint64_t pos = all8(__ballot(l1 > delta)) | all8(__ballot(l2 > delta)) |
+                             all8(__ballot(l3 > delta)) | all8(__ballot(l4 > delta));
+        culled = neg & pos;
+    }
     for (int f = f0; f < f1; ++f) {
+        if ((culled >> (8 * (f - f0))) & 1) continue;      // wave-uniform
         const double *P = inv_pose + 16 * (int64_t)f;
         const float *dimg = depth + (int64_t)depth_index[f] * hw;
         const int mi = maskbits ? frame_mask[f] : -1;
@@ -169,6 +211,39 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
             if (viewed_count && vcount[j]) atomicAdd(viewed_count + n, vcount[j]);
         }
     }
+}
+
+// Bounding boxes of the sweep's point tiles (one wave of project_views_kernel = kPPT words = 256 consecutive points
+// of the spatially sorted cloud): bounds[t] = (xmin, ymin, zmin, xmax, ymax, zmax).  NaN coordinates are ignored
+// (such a point is never in bounds), an empty tile gives (+inf, -inf) and is never culled.
+__global__ __launch_bounds__(kBlock) void point_tile_bounds_kernel(const double *__restrict__ xyz, int64_t n_points,
+                                                                    int64_t n_pad, int64_t n_tiles,
+                                                                    double *__restrict__ bounds)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int j = 0; j < kPPT; ++j) {
+        const int64_t n = (t * kPPT + j) * kWave + lane;
+        if (n < n_points)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double v = xyz[a * n_pad + n];
+                lo[a] = fmin(lo[a], v);
+                hi[a] = fmax(hi[a], v);
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            lo[a] = fmin(lo[a], __shfl_xor(lo[a], d));
+            hi[a] = fmax(hi[a], __shfl_xor(hi[a], d));
+        }
+    if (lane < 3) bounds[6 * t + lane] = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lo[2];
+    else if (lane < 6) bounds[6 * t + lane] = lane == 3 ? hi[0] : lane == 4 ? hi[1] : hi[2];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -385,7 +460,8 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
                                  const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
                                  const int32_t *frame_flags,
                                  uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
-                                 int32_t *masked_count, int32_t *viewed_count, void *stream)
+                                 int32_t *masked_count, int32_t *viewed_count, const double *tile_bounds,
+                                 void *stream)
 {
     BFF_REQUIRE(n_points >= 0 && n_pad >= n_points && n_frames >= 0, "bff_project_views: bad sizes");
     BFF_REQUIRE(height > 0 && width > 0, "bff_project_views: bad image size");
@@ -411,11 +487,24 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
         hipExtLaunchKernelGGL(project_views_kernel<uint32_t>, grid, dim3(kBlock), 0, as_stream(stream), ev0, ev1, 0,
             xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
             (const uint32_t *)maskbits, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
-            chunk_mask, mw, masked_count, viewed_count);
+            chunk_mask, mw, masked_count, viewed_count, tile_bounds);
     else
         hipExtLaunchKernelGGL(project_views_kernel<uint64_t>, grid, dim3(kBlock), 0, as_stream(stream), ev0, ev1, 0,
             xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
             (const uint64_t *)maskbits, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
-            chunk_mask, mw, masked_count, viewed_count);
+            chunk_mask, mw, masked_count, viewed_count, tile_bounds);
     return launched("bff_project_views");
 }
+
+extern "C" int bff_point_tile_bounds(const double *xyz, int64_t n_points, int64_t n_pad, double *bounds, void *stream)
+{
+    BFF_REQUIRE(n_points >= 0 && n_pad >= n_points, "bff_point_tile_bounds: bad sizes");
+    if (n_points == 0) return BFF_OK;
+    BFF_REQUIRE(xyz && bounds, "bff_point_tile_bounds: null pointer");
+    const int64_t n_tiles = ceil_div(n_points, (int64_t)kPPT * kWave);
+    point_tile_bounds_kernel<<<(unsigned)ceil_div(n_tiles, kBlock / kWave), kBlock, 0, as_stream(stream)>>>(
+        xyz, n_points, n_pad, n_tiles, bounds);
+    return launched("bff_point_tile_bounds");
+}
+
+extern "C" int bff_point_tile_size(void) { return kPPT * kWave; }

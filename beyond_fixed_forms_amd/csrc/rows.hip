@@ -4,9 +4,12 @@
 // ANDNOT on words, cardinalities are popcounts, the {0,1} matmuls of the reference
 // (F @ F.T, projection_2d_to_3d.py:159; mask_1 @ mask_2.T, refinement.py:84) are
 // popcount(a & b) accumulated over words -- exact integers, 1/32 of the bytes of the float form.
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 
 #include "common.h"
+
+static thread_local hipEvent_t g_merge_start = nullptr, g_merge_stop = nullptr;   // bff_profile_next_merge
 
 namespace bff {
 
@@ -249,7 +252,10 @@ __global__ __launch_bounds__(256) void tile_masks_kernel(const uint64_t *__restr
                                                           uint64_t *__restrict__ tmask, const uint32_t *__restrict__ hist,
                                                           uint32_t *__restrict__ hist_sorted, int n_pos,
                                                           const int32_t *__restrict__ area,
-                                                          uint32_t *__restrict__ tile_hmax, int32_t *__restrict__ tile_amin)
+                                                          uint32_t *__restrict__ tile_hmax, int32_t *__restrict__ tile_amin,
+                                                          const int32_t *__restrict__ label_id,
+                                                          int32_t *__restrict__ row_sorted, int32_t *__restrict__ area_sorted,
+                                                          int32_t *__restrict__ label_sorted)
 {
     __shared__ uint32_t s_hmax[kBins];
     __shared__ int s_amin;
@@ -279,6 +285,11 @@ __global__ __launch_bounds__(256) void tile_masks_kernel(const uint64_t *__restr
     }
     if (q == 0) {
         int a = row >= 0 ? area[row] : 0;
+        if (row_sorted) {                          // position-indexed copies: the tile pass loads them coalesced
+            row_sorted[pos] = row;
+            area_sorted[pos] = a;
+            label_sorted[pos] = row >= 0 ? label_id[row] : -1;
+        }
         a = a > 0 ? a : 0x7fffffff;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) a = min(a, __shfl_xor(a, d));
@@ -617,6 +628,61 @@ __global__ __launch_bounds__(256) void tile_pair_filter_kernel(const uint32_t *_
     if (possible) list[base + __popcll(bal & ((1ull << lane) - 1))] = t;
 }
 
+// Row-level bound for the tile pairs that survived the tile-level one: one wave per listed pair, lane k = row k of
+// tile A (then of tile B).  Row i of A against the bin-wise maxima of tile B: I(i, j) <= u_i = sum_b min(h_i[b],
+// maxB[b]) for every j of B and a_j >= aminB, so IoU(i, j) <= min(u_i, a_i) / (a_i + aminB - min(u_i, a_i)) whenever the
+// denominator is positive (same monotone float32 expression as the exact test).  Rows that fail cannot have an edge
+// into the other tile.  Pairs in which some row of A and some row of B pass are appended to list2 together with
+// the two 64-bit pass masks; most pairs end here, at the cost of one wave instead of a 256-thread block.
+__global__ __launch_bounds__(256) void tile_pair_rows_kernel(const uint32_t *__restrict__ hist, int n_pos,
+                                                              const int32_t *__restrict__ area_sorted,
+                                                              const uint32_t *__restrict__ tile_hmax,
+                                                              const int32_t *__restrict__ tile_amin, int n_tiles, float thr,
+                                                              const int32_t *__restrict__ list1,
+                                                              const int32_t *__restrict__ count1,
+                                                              int32_t *__restrict__ list2, uint64_t *__restrict__ pass2,
+                                                              int32_t *__restrict__ count2)
+{
+    const int lane = lane_id();
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= *count1) return;                                      // wave-uniform
+    const int t = list1[e];
+    int bi, d;
+    tile_pair_of(t, n_tiles, bi, d);
+    const int bj = bi + d;
+    constexpr int kBP = kBins / 2;
+    // lane b holds bin b of both tiles' maxima; read back per bin pair with a wave broadcast
+    const uint32_t hmA = tile_hmax[(int64_t)bi * kBins + lane], hmB = tile_hmax[(int64_t)bj * kBins + lane];
+    const int aA = area_sorted[bi * kT + lane], aB = area_sorted[bj * kT + lane];
+    const int aminA = tile_amin[bi], aminB = tile_amin[bj];
+    uint32_t uA = 0, uB = 0;
+#pragma unroll 8
+    for (int b = 0; b < kBP; ++b) {
+        const uint32_t wa = hist[(int64_t)b * n_pos + bi * kT + lane];
+        const uint32_t wb = hist[(int64_t)b * n_pos + bj * kT + lane];
+        const uint32_t mB0 = __shfl(hmB, 2 * b), mB1 = __shfl(hmB, 2 * b + 1);
+        const uint32_t mA0 = __shfl(hmA, 2 * b), mA1 = __shfl(hmA, 2 * b + 1);
+        uA += min(wa & 0xffffu, mB0) + min(wa >> 16, mB1);
+        uB += min(wb & 0xffffu, mA0) + min(wb >> 16, mA1);
+    }
+    // padding positions carry area 0 and an all-zero histogram: with thr >= 0 they fail (0/x or NaN), with thr < 0
+    // the tile pass ignores them by their row index (-1)
+    auto passes = [&](uint32_t u, int a_self, int a_other) {
+        const float fi = (float)min((int)u, a_self);
+        const float den = (float)a_self + (float)a_other - fi;
+        return !(den > 0.0f) || (__fdiv_rn(fi, den) > thr);
+    };
+    const uint64_t pa = __ballot(passes(uA, aA, aminB));
+    const uint64_t pb = __ballot(passes(uB, aB, aminA));
+    if (!pa || !pb) return;
+    if (lane == 0) {
+        const int at = atomicAdd(count2, 1);
+        list2[at] = t;
+        pass2[2 * at] = pa;
+        pass2[2 * at + 1] = pb;
+    }
+}
+
 // diagnostics only: thread 0 adds the cycles since *t0 to diag[slot] (>> 6 to stay inside int32) and restarts the clock
 __device__ __forceinline__ void diag_lap(int32_t *diag, int slot, long long *t0)
 {
@@ -627,25 +693,46 @@ __device__ __forceinline__ void diag_lap(int32_t *diag, int slot, long long *t0)
     }
 }
 
+// Disjoint sets over the 128 rows of ONE tile pair, in LDS (ids 0..63 = rows of A, 64..127 = rows of B; links go
+// to the smaller id).  They start from the global forest (rows that share a global root share a local set) and
+// absorb every edge the block proves, so that (a) a pair whose rows have meanwhile become connected inside the
+// tile is dropped without finishing its intersection and (b) only the edges that merge two local sets -- at most
+// 127 per tile pair -- are pushed into the global forest with compare-and-swap.
+__device__ __forceinline__ int local_find(volatile int *lid, int x)
+{
+    int p = lid[x];
+    while (p != x) { x = p; p = lid[x]; }
+    return x;
+}
+
+__device__ __forceinline__ bool local_union(int *lid, int a, int b)
+{
+    for (;;) {
+        a = local_find(lid, a);
+        b = local_find(lid, b);
+        if (a == b) return false;
+        if (a < b) { const int t = a; a = b; b = t; }              // a > b: hang a under b
+        if (atomicCAS(&lid[a], a, b) == a) return true;
+    }
+}
+
 template <bool kDiag>
-__device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restrict__ rows, int n, int64_t nw,
-                                                const int32_t *__restrict__ order,
+__device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t pass_b,
+                                                const uint64_t *__restrict__ rows, int n, int64_t nw,
                                                 const uint64_t *__restrict__ tmask, int mw,
                                                 const uint32_t *__restrict__ hist, int n_pos,
-                                                const int32_t *__restrict__ area,
-                                                const int32_t *__restrict__ label_id, float thr,
+                                                const int32_t *__restrict__ row_sorted,
+                                                const int32_t *__restrict__ area_sorted,
+                                                const int32_t *__restrict__ label_sorted, float thr,
                                                 int32_t *__restrict__ parent, int n_tiles,
-                                                const uint32_t *__restrict__ tile_hmax,
-                                                const int32_t *__restrict__ tile_amin,
                                                 int32_t *__restrict__ diag)
 {
     __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
     __shared__ uint16_t clist[kMaxChunks];
     __shared__ int s_cnt;
     __shared__ int rowA[kT], rowB[kT], rootA[kT], rootB[kT];
-    __shared__ int areaA[kT], areaB[kT], labA[kT], labB[kT];       // fetched once per tile pair, next to the roots
-    __shared__ uint32_t hmaxA[kBins], hmaxB[kBins];                // bin-wise maxima of the two tiles
-    __shared__ uint8_t passA[kT], passB[kT];                       // row can still have an edge into the other tile
+    __shared__ int areaA[kT], areaB[kT], labA[kT], labB[kT];       // fetched once per tile pair
+    __shared__ int lid[2 * kT];                                    // local disjoint sets, see above
     int bi, d;
     tile_pair_of(t, n_tiles, bi, d);
     const int bj = bi + d;
@@ -654,24 +741,23 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
     const int n_chunks = (int)((nw + kCW - 1) / kCW);
     long long t_lap = kDiag ? (long long)__builtin_readcyclecounter() : 0;     // kDiag: counters + phase clocks
 
+    // one round trip: position-indexed row / area / label of the 128 rows, then the roots of the rows that can
+    // still have an edge into the other tile (the others never enter a candidate pair)
     if (tid < kT) {
-        const int r = i0 + tid;
-        const int row = r < n ? (order ? order[r] : r) : -1;
+        const int row = row_sorted[i0 + tid];
+        const bool live = row >= 0 && ((pass_a >> tid) & 1);
         rowA[tid] = row;
-        areaA[tid] = row >= 0 ? area[row] : 0;
-        labA[tid] = row >= 0 ? label_id[row] : -1;
-        rootA[tid] = row >= 0 ? uf_find(parent, row) : -1;
+        areaA[tid] = area_sorted[i0 + tid];
+        labA[tid] = label_sorted[i0 + tid];
+        rootA[tid] = live ? uf_find(parent, row) : -1;
     } else if (tid < 2 * kT) {
-        const int r = j0 + tid - kT;
-        const int row = r < n ? (order ? order[r] : r) : -1;
-        rowB[tid - kT] = row;
-        areaB[tid - kT] = row >= 0 ? area[row] : 0;
-        labB[tid - kT] = row >= 0 ? label_id[row] : -2;
-        rootB[tid - kT] = row >= 0 ? uf_find(parent, row) : -2;
-    } else if (tid < 3 * kT) {
-        hmaxA[tid - 2 * kT] = tile_hmax[(int64_t)bi * kBins + tid - 2 * kT];
-    } else {
-        hmaxB[tid - 3 * kT] = tile_hmax[(int64_t)bj * kBins + tid - 3 * kT];
+        const int k = tid - kT;
+        const int row = row_sorted[j0 + k];
+        const bool live = row >= 0 && ((pass_b >> k) & 1);
+        rowB[k] = row;
+        areaB[k] = area_sorted[j0 + k];
+        labB[k] = label_sorted[j0 + k];
+        rootB[k] = live ? uf_find(parent, row) : -2;
     }
     // histogram bound (see merge_adjacency_kernel): possible edges only.  hist holds two 16-bit bins per
     // word, so one v_pk_min_u16 + one v_dot2_u32_u16 accumulates two bins of sum_b min(hist_i, hist_j).
@@ -688,36 +774,17 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
         }
     }
     __syncthreads();
-    if (kDiag) diag_lap(diag, 4, &t_lap);                                     // roots + histogram staging
-    // row-level bound, between the tile-level one and the pair-level one: row i of A against the bin-wise maxima
-    // of tile B, I(i, j) <= sum_b min(h_i[b], maxB[b]) for every j of B and a_j >= aminB (and the mirror image).
-    // Rows that fail cannot have an edge into the other tile; most listed tile pairs end here.
-    {
-        bool pass = false;
-        if (tid < 2 * kT) {
-            const bool is_a = tid < kT;
-            const int k = is_a ? tid : tid - kT;
-            const int row = is_a ? rowA[k] : rowB[k];
-            if (row >= 0) {
-                const uint32_t *other = is_a ? hmaxB : hmaxA;
-                uint32_t u = 0;
-#pragma unroll 8
-                for (int b = 0; b < kBP; ++b) {
-                    const uint32_t w = is_a ? ha[b][k] : hb[b][k];
-                    u += min(w & 0xffffu, other[2 * b]) + min(w >> 16, other[2 * b + 1]);
-                }
-                const int a_self = is_a ? areaA[k] : areaB[k];
-                const int a_other = is_a ? tile_amin[bj] : tile_amin[bi];
-                const float fi = (float)min((int)u, a_self);
-                const float den = (float)a_self + (float)a_other - fi;
-                pass = !(den > 0.0f) || (__fdiv_rn(fi, den) > thr);
+    if (kDiag) diag_lap(diag, 4, &t_lap);                                     // rows, roots, histogram staging
+    // local sets start from the global forest: a live row joins the first live row of the tile pair with its root
+    if (tid < 2 * kT) {
+        const int mine = tid < kT ? rootA[tid] : rootB[tid - kT];
+        int first = tid;
+        if (mine >= 0)
+            for (int q = 0; q < tid; ++q) {
+                const int other = q < kT ? rootA[q] : rootB[q - kT];
+                if (other == mine) { first = q; break; }
             }
-            if (is_a) passA[k] = pass; else passB[k] = pass;
-        }
-        const int any_a = __syncthreads_or(pass && tid < kT);
-        const int any_b = __syncthreads_or(pass && tid >= kT);
-        if (kDiag) diag_lap(diag, 11, &t_lap);                     // row-level bound
-        if (!any_a || !any_b) return;                              // block-uniform
+        lid[tid] = first;
     }
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     uint32_t ub[4][4];
@@ -726,8 +793,8 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) ub[r][c] = 0;
     const us2 ones = {1, 1};
-    const uint32_t mine_a = *reinterpret_cast<const uint32_t *>(&passA[ti * 4]);     // 4 flags each
-    const uint32_t mine_b = *reinterpret_cast<const uint32_t *>(&passB[tj * 4]);
+    const uint32_t mine_a = (uint32_t)(pass_a >> (ti * 4)) & 0xFu;          // 4 flags each
+    const uint32_t mine_b = (uint32_t)(pass_b >> (tj * 4)) & 0xFu;
     if (mine_a && mine_b)
 #pragma unroll 4
     for (int b = 0; b < kBP; ++b) {
@@ -748,7 +815,7 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int i = rowA[ti * 4 + r], j = rowB[tj * 4 + c];
-            if (((mine_a >> (8 * r)) & 1) && ((mine_b >> (8 * c)) & 1) && i >= 0 && j >= 0 && i != j &&
+            if (((mine_a >> r) & 1) && ((mine_b >> c) & 1) && i >= 0 && j >= 0 && i != j &&
                 rootA[ti * 4 + r] != rootB[tj * 4 + c] && (d > 0 || ti * 4 + r < tj * 4 + c)) {
                 const int ai = areaA[ti * 4 + r], aj = areaB[tj * 4 + c];
                 const float fi = (float)min((int)ub[r][c], min(ai, aj));
@@ -824,55 +891,96 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
 #pragma unroll
         for (int q = 0; q < 8; ++q) { sa[lk][lr + 8 * q] = ra[q]; sb[lk][lr + 8 * q] = rb[q]; }
     };
+    // One pair against the intersection counted SO FAR (final = the chunk loop has ended): returns true when the
+    // pair is settled.  Already in one local set: nothing to learn.  iou(partial) > thr: the final intersection is
+    // at least the partial one and the float32 expression is monotone in it, so the edge exists (P:149-166) --
+    // record it now (the edges that merge two local sets are queued for the global forest, see flush).
+    // Otherwise keep counting; after the last chunk the count is exact and decides.
+    __shared__ int edge_cnt;
+    __shared__ uint8_t edge_a[2 * kT], edge_b[2 * kT];             // at most 127 local unions can succeed
+    if (tid == 0) edge_cnt = 0;                                    // ordered before its first use by the barriers below
+    auto settle = [&](int ia, int jb, int inter, bool final) -> bool {
+        if (local_find(lid, ia) == local_find(lid, kT + jb)) return true;
+        const float fi = (float)inter;
+        const float iou = __fdiv_rn(fi, (float)areaA[ia] + (float)areaB[jb] - fi);
+        if (iou > thr) {                                                         // labels already equal
+            if (local_union(lid, ia, kT + jb)) {
+                const int k = atomicAdd(&edge_cnt, 1);
+                edge_a[k] = (uint8_t)ia;
+                edge_b[k] = (uint8_t)jb;
+            }
+            return true;
+        }
+        return final;
+    };
+    int flushed = 0;
+    auto flush = [&]() {                                           // call after a barrier that follows the settle phase
+        const int n_edges = edge_cnt;
+        const int k = flushed + tid;
+        if (k < n_edges) {
+            uf_union(parent, rowA[edge_a[k]], rowB[edge_b[k]]);
+            if (kDiag) atomicAdd(diag + 3, 1);
+        }
+        flushed = n_edges;
+    };
     constexpr int kStep = kKW / kCW;                               // chunks per stage
     constexpr int kSparse = 3;                                     // pair-list path: at most 3 pairs per thread
+    constexpr int kCheck = 2;                                      // settle pairs every kCheck stages
     if (kDiag) diag_lap(diag, 6, &t_lap);                                     // pair / chunk lists
     if (cnt) fetch(0);
     if (n_pairs <= kSparse * 256) {
         // few candidates: accumulate only those pairs (2 LDS reads per pair word)
         int pi[kSparse], pj[kSparse], accs[kSparse];
+        unsigned open = 0;                                         // bit q: pair q of this thread is undecided
 #pragma unroll
         for (int q = 0; q < kSparse; ++q) {
             const int p = tid + q * 256;
             const int code = p < n_pairs ? plist[p] : 0;
             pi[q] = code >> 8; pj[q] = code & 255; accs[q] = 0;
+            if (p < n_pairs) open |= 1u << q;
         }
-        const int n_mine = (n_pairs - tid + 255) / 256;            // pairs this thread really owns (<= kSparse)
+        int stages_done = 0;
         for (int g = 0; g < cnt; g += kStep) {
             stage();
             __syncthreads();
             if (g + kStep < cnt) fetch(g + kStep);
 #pragma unroll
             for (int q = 0; q < kSparse; ++q)
-                if (q < n_mine) {
+                if ((open >> q) & 1) {
                     int a2 = 0;
 #pragma unroll 8
                     for (int kk = 0; kk < kKW; ++kk) a2 += popc64(sa[kk][pi[q]] & sb[kk][pj[q]]);
                     accs[q] += a2;
                 }
-            __syncthreads();
-        }
+            const bool last = g + kStep >= cnt;
+            if (++stages_done % kCheck == 0 || last) {
 #pragma unroll
-        for (int q = 0; q < kSparse; ++q)
-            if (q < n_mine) {
-                const int i = rowA[pi[q]], j = rowB[pj[q]];
-                const float fi = (float)accs[q];
-                const float iou = __fdiv_rn(fi, (float)areaA[pi[q]] + (float)areaB[pj[q]] - fi);   // P:149-166
-                if (iou > thr) {
-                    uf_union(parent, i, j);
-                    if (kDiag) atomicAdd(diag + 3, 1);
-                }
+                for (int q = 0; q < kSparse; ++q)
+                    if (((open >> q) & 1) && settle(pi[q], pj[q], accs[q], last)) open &= ~(1u << q);
+                const int any_open = __syncthreads_or(open != 0);
+                flush();
+                if (!any_open) break;                              // every pair settled: the rest of the chunks is moot
+            } else {
+                __syncthreads();
             }
+        }
         if (kDiag) diag_lap(diag, 7, &t_lap);                                 // pair-list pass (incl. its unions)
         if (kDiag && tid == 0) atomicAdd(diag + 9, 1);
         return;
     }
-    // many candidates: full 4x4 register blocks
+    // many candidates: full 4x4 register blocks.  For a settle phase the 64 x 64 partial counts go through LDS (the
+    // staging image `sa` is free between two stages) and the candidate list is walked pair by pair, thread p
+    // taking pairs p, p + 256, ...: evenly spread whatever the shape of the candidate set, and a rolled loop.
     int acc[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+    int (*cnts)[kT + 1] = reinterpret_cast<int (*)[kT + 1]>(&sa[0][0]);       // 64 x 65 int32 = 16 640 B <= sizeof(sa)
+    static_assert(sizeof(int) * kT * (kT + 1) <= sizeof(sa), "partial-count image must fit the staging buffer");
+    const int n_mine = min(kT * kT / 256, max(0, (n_pairs - tid + 255) / 256));
+    unsigned open = (1u << n_mine) - 1;                            // bit q: pair tid + 256 q of plist is undecided
+    int stages_done = 0;
     for (int g = 0; g < cnt; g += kStep) {
         stage();
         __syncthreads();
@@ -888,46 +996,51 @@ __device__ __forceinline__ void merge_tile_pair(int t, const uint64_t *__restric
                 for (int c = 0; c < 4; ++c) acc[r][c] += popc64(av[r] & bv[c]);
         }
         __syncthreads();
-    }
+        const bool last = g + kStep >= cnt;
+        if (++stages_done % kCheck == 0 || last) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (cand & (1u << (4 * r + c))) {
-                const int i = rowA[ti * 4 + r], j = rowB[tj * 4 + c];
-                const float fi = (float)acc[r][c];
-                const float iou = __fdiv_rn(fi, (float)areaA[ti * 4 + r] + (float)areaB[tj * 4 + c] - fi);   // P:149-166
-                if (iou > thr) {                                                         // labels already equal
-                    uf_union(parent, i, j);
-                    if (kDiag) atomicAdd(diag + 3, 1);
-                }
+                for (int c = 0; c < 4; ++c) cnts[ti * 4 + r][tj * 4 + c] = acc[r][c];
+            __syncthreads();
+#pragma unroll 1
+            for (int q = 0; q < kT * kT / 256; ++q) {
+                const int p = tid + q * 256;
+                if (p >= n_pairs) break;
+                if (!((open >> q) & 1)) continue;
+                const int code = plist[p];
+                if (settle(code >> 8, code & 255, cnts[code >> 8][code & 255], last)) open &= ~(1u << q);
             }
+            const int any_open = __syncthreads_or(open != 0);
+            flush();
+            if (!any_open) break;
+        }
+    }
     if (kDiag) diag_lap(diag, 8, &t_lap);                                     // dense pass (incl. its unions)
     if (kDiag && tid == 0) atomicAdd(diag + 10, 1);
 }
 
 // Tile pass over the filtered list: block b takes entry b; blocks beyond the list (its length is only known on
-// the device) leave at once, without the loads and the reduction of the tile-level bound.  (A grid-stride or
-// work-queue loop around the tile pair costs 60-80 registers and a third of the occupancy: measured slower.)
+// the device) leave at once.  (A grid-stride or work-queue loop around the tile pair costs 60-80 registers and a
+// third of the occupancy: measured slower.)
 template <bool kDiag>
 __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
-                                                                const int32_t *__restrict__ order,
                                                                 const uint64_t *__restrict__ tmask, int mw,
                                                                 const uint32_t *__restrict__ hist, int n_pos,
-                                                                const int32_t *__restrict__ area,
-                                                                const int32_t *__restrict__ label_id, float thr,
+                                                                const int32_t *__restrict__ row_sorted,
+                                                                const int32_t *__restrict__ area_sorted,
+                                                                const int32_t *__restrict__ label_sorted, float thr,
                                                                 int32_t *__restrict__ parent, int n_tiles,
-                                                                const uint32_t *__restrict__ tile_hmax,
-                                                                const int32_t *__restrict__ tile_amin,
                                                                 int32_t *__restrict__ diag,
                                                                 const int32_t *__restrict__ list,
+                                                                const uint64_t *__restrict__ pass,
                                                                 const int32_t *__restrict__ count)
 {
     if ((int)blockIdx.x >= *count) return;                         // block-uniform
     long long t_start = 0;
     if (kDiag) t_start = (long long)__builtin_amdgcn_s_memrealtime();    // 100 MHz, one clock for the whole chip
-    merge_tile_pair<kDiag>(list[blockIdx.x], rows, n, nw, order, tmask, mw, hist, n_pos, area, label_id, thr, parent, n_tiles,
-                           tile_hmax, tile_amin, diag);
+    merge_tile_pair<kDiag>(list[blockIdx.x], pass[2 * blockIdx.x], pass[2 * blockIdx.x + 1], rows, n, nw, tmask, mw, hist,
+                           n_pos, row_sorted, area_sorted, label_sorted, thr, parent, n_tiles, diag);
     if (kDiag && threadIdx.x == 0 && diag[15] > 0 && (int)blockIdx.x < diag[15]) {
         // block timeline (diag[15] = capacity): start / end in 10-ns ticks (low 32 bits), at diag[16 + 2 b]
         diag[16 + 2 * blockIdx.x] = (int32_t)t_start;
@@ -1361,7 +1474,8 @@ extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t
     const int mw = (int)ceil_div(n_chunks, 64);
     // pairs with an empty intersection have IoU 0 (or NaN): they can only be skipped when 0 > thr is false
     const bool sparse = chunk_mask && !(0.0f > iou_thres);
-    if (sparse) tile_masks_kernel<<<nt, 256, 0, as_stream(stream)>>>(chunk_mask, order, n_rows, mw, tile_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+    if (sparse) tile_masks_kernel<<<nt, 256, 0, as_stream(stream)>>>(chunk_mask, order, n_rows, mw, tile_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                                                                     nullptr, nullptr, nullptr, nullptr);
     const int aw = nt;   // ceil(n_rows/64) words per adjacency row
     merge_adjacency_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, as_stream(stream)>>>(
         rows, n_rows, nw, order, sparse ? tile_mask : nullptr, mw, (sparse && !inter) ? hist : nullptr, area, label_id,
@@ -1369,15 +1483,23 @@ extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t
     return launched("bff_merge_adjacency");
 }
 
+extern "C" int64_t bff_merge_scratch_words(int32_t n_rows)
+{
+    const int64_t nt = ceil_div(n_rows > 0 ? n_rows : 1, kT), n_pos = nt * kT, total = nt * (nt + 1) / 2;
+    // sorted histogram, tile maxima, tile minima, three position-indexed row tables, two counters (+ padding),
+    // list 1, list 2, and two 64-bit pass masks per list-2 entry
+    return (kBins / 2) * n_pos + kBins * nt + nt + 3 * n_pos + 4 + total + total + 4 * total + 2;
+}
+
 extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
                                     int32_t n_order, const uint64_t *chunk_mask, uint64_t *tile_mask,
-                                    const uint32_t *hist, uint32_t *hist_sorted, const int32_t *area,
+                                    const uint32_t *hist, uint32_t *scratch, const int32_t *area,
                                     const int32_t *label_id, float iou_thres, int32_t *parent, int32_t init_parent,
                                     int32_t *comp, int32_t *diag, void *stream)
 {
     BFF_REQUIRE(n_rows >= 0 && nw >= 0 && n_order >= 0 && n_order <= n_rows, "bff_merge_components: bad sizes");
     if (n_rows == 0) return BFF_OK;
-    BFF_REQUIRE(rows && chunk_mask && tile_mask && hist && hist_sorted && area && label_id && parent &&
+    BFF_REQUIRE(rows && chunk_mask && tile_mask && hist && scratch && area && label_id && parent &&
                 (order || n_order == n_rows), "bff_merge_components: null pointer");
     const int nt = (int)ceil_div(n_order, kT);
     BFF_LIMIT((int64_t)nt * (nt + 1) / 2 < (1ll << 31), "bff_merge_components: too many rows");
@@ -1389,33 +1511,53 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
     if (n_order > 0) {
         // an empty intersection gives IoU 0 (or NaN): such pairs can only be skipped when 0 > thr is false
         const bool sparse = !(0.0f > iou_thres);
-        // scratch carved from hist_sorted: [64][nt*64] sorted histograms, then [nt][64] tile maxima, then [nt] min areas
-        uint32_t *tile_hmax = hist_sorted + (size_t)kBins * nt * kT;
+        const int64_t n_pos = (int64_t)nt * kT, total = (int64_t)nt * (nt + 1) / 2;
+        // scratch layout (int32 words), see bff_merge_scratch_words
+        uint32_t *hist_sorted = scratch;
+        uint32_t *tile_hmax = hist_sorted + (size_t)(kBins / 2) * n_pos;
         int32_t *tile_amin = reinterpret_cast<int32_t *>(tile_hmax + (size_t)nt * kBins);
-        tile_masks_kernel<<<nt, 256, 0, st>>>(chunk_mask, order, n_order, mw, tile_mask, hist, hist_sorted, nt * kT, area,
-                                             tile_hmax, tile_amin);
+        int32_t *row_sorted = tile_amin + nt;
+        int32_t *area_sorted = row_sorted + n_pos;
+        int32_t *label_sorted = area_sorted + n_pos;
+        int32_t *counts = label_sorted + n_pos;                        // [0] list 1, [1] list 2
+        int32_t *list1 = counts + 4;
+        int32_t *list2 = list1 + total;
+        uintptr_t p2 = reinterpret_cast<uintptr_t>(list2 + total);
+        uint64_t *pass2 = reinterpret_cast<uint64_t *>((p2 + 7) & ~(uintptr_t)7);
+        tile_masks_kernel<<<nt, 256, 0, st>>>(chunk_mask, order, n_order, mw, tile_mask, hist, hist_sorted, (int)n_pos, area,
+                                             tile_hmax, tile_amin, label_id, row_sorted, area_sorted, label_sorted);
         constexpr int kStrides = 4;                                    // 1, 2, 3, 5 (more strides measured no faster)
         dim3 sgrid((unsigned)ceil_div(n_order, 4), kStrides);
         uf_skeleton_kernel<<<sgrid, 256, 0, st>>>(rows, n_order, nw, order, chunk_mask, mw, area, label_id, iou_thres,
                                                   parent, kStrides);
-        const int64_t total = (int64_t)nt * (nt + 1) / 2;
-        int32_t *pair_count = tile_amin + nt;                          // behind the other scratch: count, then the list
-        int32_t *pair_list = pair_count + 1;
-        hipError_t e = hipMemsetAsync(pair_count, 0, sizeof(int32_t), st);
+        hipError_t e = hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), st);
         if (e != hipSuccess) return fail((int)e, "bff_merge_components: memset: %s", hipGetErrorString(e));
         tile_pair_filter_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(tile_hmax, tile_amin, nt, (int)total,
-                                                                               iou_thres, pair_list, pair_count);
+                                                                               iou_thres, list1, counts);
+        tile_pair_rows_kernel<<<(unsigned)ceil_div(total, 4), 256, 0, st>>>(hist_sorted, (int)n_pos, area_sorted, tile_hmax,
+                                                                           tile_amin, nt, iou_thres, list1, counts,
+                                                                           list2, pass2, counts + 1);
+        const hipEvent_t ev0 = g_merge_start, ev1 = g_merge_stop;      // attached to the dispatch itself when set
+        g_merge_start = g_merge_stop = nullptr;
         if (diag)       // counters + phase clocks compiled in (a couple of registers more: one wave less per SIMD)
-            merge_components_kernel<true><<<(unsigned)total, 256, 0, st>>>(
-                rows, n_order, nw, order, sparse ? tile_mask : nullptr, mw, hist_sorted, nt * kT, area, label_id, iou_thres,
-                parent, nt, tile_hmax, tile_amin, diag, pair_list, pair_count);
+            hipExtLaunchKernelGGL(merge_components_kernel<true>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
+                rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
+                label_sorted, iou_thres, parent, nt, diag, list2, pass2, counts + 1);
         else
-            merge_components_kernel<false><<<(unsigned)total, 256, 0, st>>>(
-                rows, n_order, nw, order, sparse ? tile_mask : nullptr, mw, hist_sorted, nt * kT, area, label_id, iou_thres,
-                parent, nt, tile_hmax, tile_amin, nullptr, pair_list, pair_count);
+            hipExtLaunchKernelGGL(merge_components_kernel<false>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
+                rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
+                label_sorted, iou_thres, parent, nt, (int32_t *)nullptr, list2, pass2, counts + 1);
     }
     if (comp) uf_flatten_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows, comp);
     return launched("bff_merge_components");
+}
+
+// Profiling aid (bench.py): events attached to the next tile-pass dispatch of this host thread.
+extern "C" int bff_profile_next_merge(void *start_event, void *stop_event)
+{
+    g_merge_start = reinterpret_cast<hipEvent_t>(start_event);
+    g_merge_stop = reinterpret_cast<hipEvent_t>(stop_event);
+    return BFF_OK;
 }
 
 extern "C" int bff_permute_bits(const uint64_t *rows_in, int32_t n_rows, int64_t nw_in, const int32_t *idx,

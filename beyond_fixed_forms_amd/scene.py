@@ -112,6 +112,7 @@ class DeviceScene:
     n_label_ids: int = 1                 # number of distinct label strings
     stage1: Optional[dict] = None
     unsort: Optional[torch.Tensor] = None   # i32 [N]: position of original point o in the sorted cloud (None = unsorted)
+    tile_bounds: Optional[torch.Tensor] = None   # f64 [tiles][6]: boxes of the sweep's point tiles (frustum culling)
 
 
 def viewed_frame_ids(color_files, downsample_ratio):
@@ -237,9 +238,14 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True)
         depth_dev = frames_to_device(depth_list, np.float32, torch.float32)
     else:
         depth_dev = torch.zeros((0, h * w), dtype=torch.float32, device=dev)
+    xyz_dev = t(soa, torch.float64)
+    bounds = None
+    if dev.type == "cuda" and n:
+        from . import _lib
+        bounds = _lib.point_tile_bounds(xyz_dev, n)      # built once per scene, next to the spatial sort it relies on
     return DeviceScene(
         scene_id=scene.scene_id, n_points=n, nw=nw, height=h, width=w, cam_intr=cam_intr,
-        xyz=t(soa, torch.float64),
+        xyz=xyz_dev, tile_bounds=bounds,
         depth=depth_dev,
         inv_pose=t(np.stack(inv).reshape(nf, 16) if nf else np.zeros((0, 16)), torch.float64),
         depth_index=t(np.array(d_idx, np.int32), torch.int32), frame_mask=t(np.array(f_mask, np.int32), torch.int32),

@@ -92,6 +92,7 @@ int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const 
  *   masked_count int32 [n_points], += number of masks of the frame containing the visible point
  *                (P:459-461 adds 1 per mask, not per view); may be NULL
  *   viewed_count int32 [n_points], += visibility for frames with flag bit0; may be NULL
+ *   tile_bounds  optional float64 table from bff_point_tile_bounds (frustum culling per wave and frame); NULL = off
  *
  * Arithmetic contract (bit-exact with NumPy/OpenBLAS float64 as used by the reference):
  *   c_i = fma chain over k = 0..3 of inv_pose[i][k] * (x, y, z, 1)[k] starting from +0.0;
@@ -108,7 +109,16 @@ int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
                       const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
                       const int32_t *frame_flags,
                       uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
-                      int32_t *masked_count, int32_t *viewed_count, void *stream);
+                      int32_t *masked_count, int32_t *viewed_count, const double *tile_bounds, void *stream);
+
+/* Frustum culling for bff_project_views (optional, exact).  bounds: float64 [ceil(n_points / bff_point_tile_size())][6]
+ * = (xmin, ymin, zmin, xmax, ymax, zmax) of every tile of bff_point_tile_size() consecutive points -- the points
+ * one wave of the sweep owns.  Given the table, a wave skips a frame when the box of its points cannot contain a
+ * point whose pixel is in bounds (a conservative half-space test of the 8 corners against the four image
+ * borders, both in front of and behind the camera: the reference has no z > 0 test, P:57-67); results are
+ * bit-identical with and without it.  It pays when the cloud is spatially sorted (scene.morton_order). */
+int bff_point_tile_bounds(const double *xyz, int64_t n_points, int64_t n_pad, double *bounds, void *stream);
+int bff_point_tile_size(void);
 
 /* Profiling aid.  bff_profile_next_sweep(start, stop): the next bff_project_views launch of the calling host
  * thread carries the two events on its dispatch (hipExtLaunchKernelGGL), so that bff_event_elapsed_ms(start,
@@ -190,13 +200,21 @@ int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const 
  * i's component.  Rows with an empty
  * adjacency row (area 0, or thr >= 1) form singleton components here; the host turns them into the
  * reference's empty lists (it knows area and thr).  All other arguments as for bff_merge_adjacency;
- * chunk_mask, tile_mask and hist are required; hist_sorted is scratch, uint32 [64*64*nt + 65*nt + 1 + nt*(nt+1)/2] with
- * nt = ceil(n_rows/64);
- * diag (optional, NULL in production): int32 [4], zeroed by the caller, += {tile pairs evaluated, chunks
- * visited, candidate pairs tested exactly, unions performed}. */
+ * chunk_mask, tile_mask and hist are required; scratch: uint32 [bff_merge_scratch_words(n_rows)] (sorted histograms,
+ * tile bounds, position-indexed row tables, the two tile-pair lists).
+ * Inside a tile pair the block keeps disjoint sets of its 128 rows in LDS (started from the global forest): every
+ * few chunks it settles the pairs whose PARTIAL intersection already passes the IoU test (the float32 expression is
+ * monotone in I, so the edge exists) or whose rows have become connected meanwhile, and stops as soon as no pair is
+ * open; only edges that merge two local sets are pushed into `parent`.
+ * diag (optional, NULL in production): int32 [16 + 2 * capacity], zeroed by the caller: += {tile pairs evaluated,
+ * chunks visited, candidate pairs, unions, phase clocks ...} (scripts/diag_merge_phases.py). */
+int64_t bff_merge_scratch_words(int32_t n_rows);
+/* Profiling aid: the next tile-pass dispatch of bff_merge_components on this host thread carries the two events
+ * (like bff_profile_next_sweep). */
+int bff_profile_next_merge(void *start_event, void *stop_event);
 int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order, int32_t n_order,
                          const uint64_t *chunk_mask, uint64_t *tile_mask, const uint32_t *hist,
-                         uint32_t *hist_sorted, const int32_t *area, const int32_t *label_id, float iou_thres,
+                         uint32_t *scratch, const int32_t *area, const int32_t *label_id, float iou_thres,
                          int32_t *parent, int32_t init_parent, int32_t *comp, int32_t *diag, void *stream);
 
 /* rows_out[r] bit o = rows_in[r] bit idx[o], o < n_out (bit gather).  Undoes the spatial point sort the

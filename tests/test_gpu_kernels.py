@@ -131,6 +131,11 @@ def run_view(lib, xyz, inv_pose, k33, depth, masks):
     lib.project_views(*args, maskbits_from_dense.last_sparse, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows2, mc2, vc2,
                       segmap=maskbits_from_dense.last_segmap)
     assert torch.equal(rows2, rows) and torch.equal(mc2, mc) and torch.equal(vc2, vc)
+    # and with the frustum-culling table of the point tiles (boxes may hold inf / 1e300 / denormals here)
+    rows3, mc3, vc3 = torch.zeros_like(rows), torch.zeros_like(mc), torch.zeros_like(vc)
+    lib.project_views(*args, bits, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows3, mc3, vc3,
+                      tile_bounds=lib.point_tile_bounds(args[0], n))
+    assert torch.equal(rows3, rows) and torch.equal(mc3, mc) and torch.equal(vc3, vc)
     return unpack(rows, n), mc.cpu().numpy(), vc.cpu().numpy()
 
 
@@ -614,7 +619,7 @@ def test_cosine_golden_on_device(lib):
     e16 = torch.from_numpy(z["clip.emb_f16"][:, 0, :].copy()).half()
     got32 = lib.cosine_rows(e32.to(DEV), e32.to(DEV)).cpu().numpy().astype(np.float64)
     assert np.abs(got32 - z["clip.sims_f32"]).max() <= 1e-4              # north_star's tolerance
-    assert np.abs(got32 - z["clip.sims_f32"]).max() <= 2e-7              # observed: the last ulp of a float32 dot
+    assert np.abs(got32 - z["clip.sims_f32"]).max() <= 5e-7              # observed: 2 float32 ulps at |cos| ~ 1 (dot, norms and their product each round once)
     got16 = lib.cosine_rows(e16.to(DEV), e16.to(DEV)).cpu().numpy().astype(np.float64)
     assert np.array_equal(got16, got16.astype(np.float16).astype(np.float64))       # float16 values
     assert np.abs(got16 - z["clip.sims_f16"]).max() <= 2.0 ** -11        # one float16 ulp below 1.0
@@ -641,7 +646,7 @@ def test_cosine_golden_on_device(lib):
     sub = lib.cosine_rows(a[:50].to(DEV), b.to(DEV)).cpu().double()
     assert (sub - ref[:50]).abs().max().item() <= 2.0 ** -11
     sub32 = lib.cosine_rows(a[:50].float().to(DEV), b.float().to(DEV)).cpu().double()
-    assert (sub32 - ref[:50]).abs().max().item() <= 2e-7
+    assert (sub32 - ref[:50]).abs().max().item() <= 5e-7
 
 
 @pytest.mark.parametrize("thr", [-1.0, -0.5, 0.0])
@@ -671,3 +676,55 @@ def test_components_negative_threshold_with_empty_tiles(lib, thr):
         assert groups_from_labels(comp, self_loop) == exp
     if thr < 0:
         assert any(len(g) > 100 for g in exp)                    # the empty rows did join
+
+
+def test_frustum_culling_is_exact(lib):
+    """Sweep with and without the tile boxes on a spatially sorted cloud, cameras INSIDE the cloud, looking in all
+    directions (most tiles are culled for most frames; boxes straddle the camera plane, lie behind it, or touch an
+    image border): rows and both counters are bit-identical.  Points behind the camera that project in bounds and
+    pass the depth test (no z > 0 test in the reference, P:57-67) are present on purpose."""
+    from beyond_fixed_forms_amd.scene import morton_order
+    rng = np.random.default_rng(31)
+    n, h, w, m, nf = 60_000, 120, 160, 6, 24
+    xyz = rng.uniform(-3, 3, (n, 3))
+    xyz[:2000] = rng.normal(0, 0.02, (2000, 3))                       # a dense blob around the first camera
+    xyz = xyz[morton_order(xyz)]
+    nw, n_pad = (n + 63) // 64, ((n + 1023) // 1024) * 1024
+    soa = np.zeros((3, n_pad)); soa[:, :n] = xyz.T
+    k33 = np.array([[140.3, 0.0, 79.5], [0.0, 140.3, 59.5], [0.0, 0.0, 1.0]])
+    inv = []
+    for f in range(nf):
+        a, b = rng.uniform(-np.pi, np.pi, 2)
+        rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        pose = np.eye(4)
+        pose[:3, :3] = rz @ ry
+        pose[:3, 3] = 0 if f == 0 else rng.uniform(-2.5, 2.5, 3)
+        inv.append(np.linalg.inv(pose))
+    depth = rng.uniform(0.02, 5.0, (nf, h * w)).astype(np.float32)
+    depth[0] = 0.03                                                   # tiny depth: points just behind camera 0 pass |z - d| < 0.08
+    masks = [rng.random((m, h * w)) < 0.5 for _ in range(nf)]
+    bits, wb = maskbits_from_dense(lib, masks, h * w)
+    i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)
+    xs = torch.from_numpy(soa).to(DEV)
+    args = (xs, n, torch.from_numpy(np.stack(inv).reshape(nf, 16)).to(DEV), k33, torch.from_numpy(depth).to(DEV),
+            i32(list(range(nf))), h, w, 0.08, bits, wb, i32(list(range(nf))), i32([m * f for f in range(nf)]),
+            i32([m] * nf), i32([1] * nf))
+    out = []
+    for tb in (None, lib.point_tile_bounds(xs, n)):
+        rows = torch.zeros((m * nf, nw), dtype=torch.int64, device=DEV)
+        mc = torch.zeros(n, dtype=torch.int32, device=DEV)
+        vc = torch.zeros(n, dtype=torch.int32, device=DEV)
+        lib.project_views(*args, rows, mc, vc, tile_bounds=tb)
+        out.append((rows, mc, vc))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert int(out[0][2].sum().item()) > 1000
+    # the boxes themselves
+    tb = lib.point_tile_bounds(xs, n).cpu().numpy()
+    for t in (0, 7, tb.shape[0] - 1):
+        pts = xyz[256 * t: 256 * (t + 1)]
+        assert np.array_equal(tb[t, :3], pts.min(0)) and np.array_equal(tb[t, 3:], pts.max(0))
+    # behind-the-camera visibility exists in this data (otherwise the back cone would be untested)
+    cam0 = (inv[0] @ np.concatenate([xyz, np.ones((n, 1))], 1).T).T
+    assert ((cam0[:, 2] < 0) & (np.abs(cam0[:, 2] - 0.03) < 0.08)).sum() > 10

@@ -410,8 +410,8 @@ def test_similarity_set_near_ties(api, enc_dtype):
         assert got_set == exp_set and dbg["sim_thres"] == odbg["sim_thres"]
     else:
         assert len(exp_set) == k                                          # 2e-6 apart: all distinct in float32
-        assert np.abs(np.array(got_set) - np.array(exp_set)).max() <= 2e-7
-        assert abs(dbg["sim_thres"] - odbg["sim_thres"]) <= 2e-7
+        assert np.abs(np.array(got_set) - np.array(exp_set)).max() <= 5e-7      # a few float32 ulps; the values are >= 2e-6 apart
+        assert abs(dbg["sim_thres"] - odbg["sim_thres"]) <= 5e-7
     # same order of the labels along the sorted set -> same index -> same masks dropped
     for (sid, _, _) in scenes_p:
         same(fin[sid].to_dict(), fexp[sid])
