@@ -18,8 +18,12 @@ from __future__ import annotations
 
 import os
 
-os.environ.setdefault("OPENBLAS_NUM_THREADS", "16")
-os.environ.setdefault("OMP_NUM_THREADS", "16")
+try:
+    _NCPU = min(len(os.sched_getaffinity(0)), 32)
+except AttributeError:
+    _NCPU = min(os.cpu_count() or 1, 32)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", str(_NCPU))
+os.environ.setdefault("OMP_NUM_THREADS", str(_NCPU))
 
 import argparse
 import copy
@@ -65,13 +69,14 @@ def bank_encoder(bank, index):
     return enc
 
 
-def cpu_baseline(scene, cfg, enc, n_sample_views=100, threads=16):
+def cpu_baseline(scene, cfg, enc, n_sample_views=100, threads=None):
     """Oracle (CPU restatement of the reference) on a bounded sample (~10-30 s of CPU work): the first
     `n_sample_views` frames of the same scene at full N / HxW / M, whole path (projection, aggregation of
     the sample's instances, ratio sweep, filters, refinement); the projection time is scaled linearly to the
     scene's views, which favours the CPU (its aggregation grows quadratically with the instance count)."""
     from oracle.projection_ref import project_scene_ref
     from oracle.refinement_ref import refine_class_ref
+    threads = threads or min(host_cores(), 32)
     torch.set_num_threads(threads)
     sub = copy.copy(scene)
     sub.mask_2d = [dict(f) for f in scene.mask_2d[:n_sample_views]]
@@ -93,10 +98,12 @@ def cpu_baseline(scene, cfg, enc, n_sample_views=100, threads=16):
     n_views = len(scene.mask_2d)
     est_scene_s = (t1 - t0) * n_views / max(1, len(sub.mask_2d)) + (t2 - t1)
     return {"stages_sample_s": {k: round(v, 4) for k, v in stages.items()},     # SURVEY 8(d) stages (i)-(v), on the sample
-            "value": 1.0 / est_scene_s, "unit": "scenes/s", "cores": 16, "kind": "port",
+            "value": 1.0 / est_scene_s, "unit": "scenes/s", "cores": threads, "kind": "port",
             "sample": f"oracle projection+refinement on {len(sub.mask_2d)} of {n_views} mask views and "
                       f"{(len(sub.color_files) + ratio - 1) // ratio} viewed frames at full N/HxW/M ({t2 - t0:.1f} s CPU), "
-                      f"projection scaled linearly to {n_views} views; the reference's O(Ins^2) label loop and "
+                      f"projection scaled linearly to {n_views} views; starts from the reference's host formats and so "
+                      f"INCLUDES the RLE decode of the 2-D masks (the GPU `value` starts from HBM-resident run tables; "
+                      f"see host_inclusive for the GPU rate from host arrays); the reference's O(Ins^2) label loop and "
                       f"O(Ins^4) closure are NOT included (oracle uses integer ids and a frontier search)",
             "sample_seconds": t2 - t0}
 
@@ -111,7 +118,7 @@ def cpu_stagewise(args):
     O(Ins^4)), clearly labelled as such."""
     import functools
     say = functools.partial(print, flush=True)
-    threads = int(os.environ.get("BFF_CPU_THREADS", "16"))      # the GPU box gives one GPU's share of the host
+    threads = int(os.environ.get("BFF_CPU_THREADS", str(min(host_cores(), 32))))      # the GPU box gives one GPU's share of the host
     torch.set_num_threads(threads)
     say(f"host: {os.cpu_count()} logical cores; torch threads {threads}; model:",
         next((ln.split(":")[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "?"))
@@ -202,6 +209,37 @@ def bench_cosine(args):
         "max_abs_err_vs_f64": err}))
 
 
+def host_cores():
+    """Logical cores this process may run on (the GPU box gives a 1-GPU job a share of the host)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+SCENE_VARIANTS = [
+    # the scenes rotated through the timed loop (seed offsets); "many": 40 smaller objects, one exact full-silhouette
+    # mask per visible object and view -> many stage-2 instances survive the filters, so the back half, the
+    # refinement and the gather are timed on K >> 1; "default": the generator SURVEY 8(d) describes
+    dict(kind="default"), dict(kind="many", cut_masks=False, n_objects=40, distinct_masks=True, dilate=False),
+    dict(kind="default"), dict(kind="many", cut_masks=False, n_objects=40, distinct_masks=True, dilate=False),
+]
+
+
+def merge_traffic(ds, cfg, dev):
+    """Counters of one tile pass (a diagnostic launch outside the timed region): tile pairs that reached the exact
+    stage, 512-point chunks staged through LDS, candidate row pairs, unions pushed into the global forest."""
+    fr = projection_front(ds, cfg, fast=False)
+    area, _mw, cmask, hist, sig = _lib.row_stats(fr.rows, fr.cmask)
+    order = _lib.argsort_i64(sig, _lib.SIGNATURE_BITS)
+    d = torch.zeros(16, dtype=torch.int32, device=dev)
+    _lib.merge_components(fr.rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist, diag=d)
+    v = d.cpu().tolist()
+    if fr.arena is not None:
+        fr.arena.release(fr.rows, fr.cmask)
+    return dict(tile_pairs=v[0], chunk_visits=v[1], candidate_pairs=v[2], unions=v[3])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,8 +251,12 @@ def main():
                     help="print the stage-wise CPU (oracle) timings of SURVEY 8(d) for --shape and exit")
     ap.add_argument("--cpu-sample-views", type=int, default=100)
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="finish every scene before starting the next (default: the GPU-only front half of the next "
+                    help="finish every scene before starting the next (default: the device work of the next "
                          "scene is issued on a second HIP stream while the host finishes the current one)")
+    ap.add_argument("--scenes", type=int, default=4, help="resident scenes rotated through the timed loop")
+    ap.add_argument("--include-upload", action="store_true",
+                    help="also report the host-inclusive rate: every step takes host arrays (reference formats, raw "
+                         "16-bit depth) through the overlapped ingestion pipeline before the device path")
     args = ap.parse_args()
     if args.shape == "c5":
         return bench_cosine(args)
@@ -239,15 +281,22 @@ def main():
     dev = f"cuda:{local_rank}"
     _lib.load()
 
-    # ---- one synthetic scene per rank (seed = rank), uploaded once: inputs resident in HBM
+    # ---- resident scenes of this rank (different seeds and two generator variants), uploaded once: inputs in HBM
     n, v, h, w, m = SHAPES[args.shape]
     t0 = time.perf_counter()
-    scene = make_scene(args.shape, seed=rank, device=dev, query=QUERY)
-    cfg = Config.with_defaults(width_2d=scene.width, height_2d=scene.height)
-    ds = prepare_scene(scene, cfg, device=dev)
-    stage1 = prepare_stage1(scene.stage1, dev)          # class-independent: uploaded with the scene
-    bank, index = make_text_bank(768, seed=0)
-    enc = bank_encoder(bank.float(), index)
+    n_scenes = max(1, args.scenes)
+    scenes, dss, stage1s = [], [], []
+    cfg = None
+    for k in range(n_scenes):
+        var = dict(SCENE_VARIANTS[k % len(SCENE_VARIANTS)])
+        var.pop("kind")
+        sc = make_scene(args.shape, seed=rank * n_scenes + k, device=dev, query=QUERY, **var)
+        cfg = Config.with_defaults(width_2d=sc.width, height_2d=sc.height)
+        scenes.append(sc)
+        dss.append(prepare_scene(sc, cfg, device=dev))
+        stage1s.append(prepare_stage1(sc.stage1, dev))          # class-independent: uploaded with the scene
+    bank, index = make_text_bank(768, seed=0)                  # float16, like CLIP text features on a GPU
+    enc = bank_encoder(bank, index)
     sim = TextSimilarity(enc, dev)
     t_setup = time.perf_counter() - t0
     exchange = bdist.ClassExchange("cpu" if rehearse else dev) if world > 1 else None     # sims + result-size bounds, one all-gather
@@ -256,13 +305,14 @@ def main():
 
     timers = KernelTimers()
     streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-
-    host = {"front_issue_s": 0.0, "back_s": 0.0}     # host wall time per half (back includes its sync waits)
+    host = {"front_issue_s": 0.0, "back_s": 0.0}     # host wall time per half (back includes its sync wait)
+    results = {}
 
     def front(i, tm=None):
         t = time.perf_counter()
+        k = i % n_scenes
         with torch.cuda.stream(streams[i % 2]):
-            fr = projection_front(ds, cfg, timers=tm)
+            fr = projection_front(dss[k], cfg, timers=tm, stage1=stage1s[k])
         host["front_issue_s"] += time.perf_counter() - t
         return fr
 
@@ -274,19 +324,21 @@ def main():
             host["back_s"] += time.perf_counter() - t
 
     def _back(i, fr):
+        k = i % n_scenes
         with torch.cuda.stream(streams[i % 2]):
-            res = projection_back(fr, stage1=stage1)     # the refinement follows: its first device pass rides along
-            fin = refine_class([(scene.scene_id, stage1, res)], cfg, QUERY, sim, dev, exchange_sims=exchange)
-            rows = fin[scene.scene_id].rows
+            res = projection_back(fr, want_groups=False)
+            fin = refine_class([(scenes[k].scene_id, stage1s[k], res)], cfg, QUERY, sim, dev, exchange_sims=exchange)
+            rows = fin[scenes[k].scene_id].rows
             if rows is None:
-                rows = torch.zeros((0, ds.nw), dtype=torch.int64, device=dev)
+                rows = torch.zeros((0, dss[k].nw), dtype=torch.int64, device=dev)
             gathered = bdist.gather_final_rows(rows, bounds=exchange.bounds if exchange is not None else None)
+        results[k] = (int(res.rows.shape[0]), int(rows.shape[0]))
         return res, fin, gathered
 
     def run_steps(k, tm=None):
         """k scenes, one after the other through the whole path.  Pipelined form: while the host works on the
-        back half of scene i (read-backs, grouping, refinement), the front half of scene i+1 (decode, sweep,
-        components: no host dependency) already runs on the other stream."""
+        back half of scene i (header, size filter, refinement bookkeeping), the device work of scene i+1 already
+        runs on the other stream."""
         out = None
         if args.no_pipeline:
             for i in range(k):
@@ -312,29 +364,37 @@ def main():
     host.update(front_issue_s=0.0, back_s=0.0)
     _lib.sync_wait_s = 0.0
     t0 = time.perf_counter()
-    res, fin, gathered = run_steps(args.steps, timers)
+    run_steps(args.steps, timers)
     fence()
     elapsed = time.perf_counter() - t0
     host_ms = {"front_issue": round(host["front_issue_s"] / args.steps * 1e3, 4),
                "back": round(host["back_s"] / args.steps * 1e3, 4),
                "of_which_waiting_for_gpu": round(_lib.sync_wait_s / args.steps * 1e3, 4)}
+    host_ms["host_work"] = round(host_ms["front_issue"] + host_ms["back"] - host_ms["of_which_waiting_for_gpu"], 4)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # the sweep kernel alone on the chip: a short strictly sequential loop after the timed region (in the
-    # pipelined loop it shares the GPU with the previous scene's back-half kernels)
+    # the two big kernels alone on the chip: a short strictly sequential loop after the timed region (in the
+    # pipelined loop they share the GPU with the other scene's kernels)
     seq_timers = KernelTimers()
     if not args.no_pipeline:
         was = args.no_pipeline
         args.no_pipeline = True
-        run_steps(min(10, args.steps), seq_timers)
+        run_steps(min(2 * n_scenes, args.steps), seq_timers)
         args.no_pipeline = was
         fence()
 
+    upload_leg = None
+    if args.include_upload and rank == 0:
+        from beyond_fixed_forms_amd.ingest import bench_host_inclusive
+        upload_leg = bench_host_inclusive(scenes, cfg, dev, QUERY, sim, steps=min(args.steps, 40))
+
     if rank == 0:
         ks = timers.summary()
+        sq = seq_timers.summary() if not args.no_pipeline else ks
+        ds = dss[0]
         n_swept = ds.n_frames
         pv = ks["project_views"]
         abytes, zbytes = algorithmic_bytes(ds, n_swept)
@@ -344,36 +404,46 @@ def main():
         if os.path.exists(tfile):
             with open(tfile) as f:
                 traffic = json.load(f).get(f"project_views_{args.shape}")
+        mt = merge_traffic(ds, cfg, dev)
+        mc_ms, mc_alone = ks["merge_components"][2], sq["merge_components"][2]
+        l2_bytes = mt["chunk_visits"] * 128 * 64            # every visited chunk: 128 rows x 8 words staged through LDS
         out = {
             "metric": "scenes/sec (2D->3D projection+refinement), 200k pts x 300 views",
             "value": world * args.steps / elapsed, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.shape}: 1 scene/GPU, {n} pts x {len(scene.mask_2d)} mask views + "
+            "config": {"workload": f"{args.shape}: 1 scene/GPU per step, {n} pts x {len(scenes[0].mask_2d)} mask views + "
                                    f"{ds.n_viewed} viewed frames @{h}x{w}, {m} masks/view (Ins={ds.n_rows}), "
-                                   f"stage-1 S1={len(scene.stage1['ins'])}, 198x768 f16 text bank",
+                                   f"stage-1 S1={len(scenes[0].stage1['ins'])}, 198x768 f16 text bank; inputs RESIDENT in "
+                                   f"HBM (uploaded before the timed region); {n_scenes} different scenes rotate through the loop",
                        "scenes_per_step": world, "sharding": "one scene per GPU, RCCL gather of final masks",
                        "pipelining": "none" if args.no_pipeline else
-                       "2 HIP streams: front half of scene i+1 overlaps the host-side back half of scene i"},
+                       "2 HIP streams: the device work of scene i+1 overlaps the host half of scene i",
+                       "scene_variants": [SCENE_VARIANTS[k % len(SCENE_VARIANTS)]["kind"] for k in range(n_scenes)]},
             "roofline": {"bound": "hbm", "kernel": "project_views_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["bytes"] if traffic else None,      # HBM bytes per launch from the PMC counters
                          "traffic_detail": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": pv[2], "launches": pv[0],
                          "survey_row_write_bytes_not_credited": zbytes,
-                         "alone_on_chip": (lambda sq: {"avg_launch_ms": sq["project_views"][2],
-                                                       "achieved": abytes / (sq["project_views"][2] * 1e-3) / 1e9,
-                                                       "frac": abytes / (sq["project_views"][2] * 1e-3) / 1e9 / HBM_PEAK_GBS})(
-                             seq_timers.summary()) if not args.no_pipeline else None},
-            "host_ms": host_ms,      # wall time of the host thread per step: issuing the front half, the back half, and the part of the back half spent blocked on the GPU
-            "kernels_ms": {k: round(vv[2], 4) for k, vv in ks.items()},   # HIP-event spans (merge_components includes its read-back)
-            "result": {"stage2_instances": int(res.rows.shape[0]),
-                       "final_masks": int(fin[scene.scene_id].rows.shape[0]) if fin[scene.scene_id].rows is not None else 0,
-                       "merged_groups": len(res.groups)},
+                         "alone_on_chip": {"avg_launch_ms": sq["project_views"][2],
+                                           "achieved": abytes / (sq["project_views"][2] * 1e-3) / 1e9,
+                                           "frac": abytes / (sq["project_views"][2] * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+            # second bound: the components' tile pass is AND + popcount over LDS-staged chunks -- not HBM, not MFMA
+            "roofline_merge": {"bound": "l2->lds staging + VALU popcount", "kernel": "merge_components_kernel",
+                               "avg_launch_ms": mc_ms, "alone_on_chip_ms": mc_alone, "launches": ks["merge_components"][0],
+                               "l2_bytes_staged": l2_bytes, "achieved": l2_bytes / (mc_alone * 1e-3) / 1e9,
+                               "peak": 34500.0, "unit": "GB/s (L2, MI355X_MICROARCH.md)",
+                               "frac": l2_bytes / (mc_alone * 1e-3) / 1e9 / 34500.0, **mt},
+            "host_ms": host_ms,      # wall time of the host thread per step: issuing, the host half, and the part of it spent blocked on the GPU
+            "kernels_ms": {k: round(vv[2], 4) for k, vv in ks.items()},   # the kernels' own durations (events on the dispatch)
+            "result": {"per_scene (stage2_instances, final_masks)": [results.get(k) for k in range(n_scenes)]},
             "setup_s": round(t_setup, 1),
         }
+        if upload_leg is not None:
+            out["host_inclusive"] = upload_leg
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cfg, enc)
+            out["cpu_baseline"] = cpu_baseline(scenes[0], cfg, bank_encoder(bank.float(), index))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

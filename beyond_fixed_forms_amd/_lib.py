@@ -50,6 +50,12 @@ SIGNATURES = {
     "bff_select_unique_rank": [_P, _L, _D, _P, _P, _P, _P],
     "bff_cosine_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
     "bff_cosine_rows": [_P, _I, _P, _I, _I, _I, _P, _P],
+    "bff_group_components": [_P, _P, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "bff_or_reduce_grouped": [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
+    "bff_resolve_overlaps_dev": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P],
+    "bff_clear_flagged_chunks_unless": [_P, _I, _L, _P, _P, _P],
+    "bff_scene_project": [_P, _P, _P, _P],
+    "bff_cloud_layout": [_P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "bff_sort_f32": [_P, _P, _L, _P, _P, _P],
     "bff_argsort_i64": [_P, _P, _P, _I, _I, _P, _P, _P],
     "bff_depth_from_u16": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P],
@@ -57,7 +63,8 @@ SIGNATURES = {
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
          "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
          "bff_point_tile_size": (c_int32, []), "bff_merge_scratch_words": (c_int64, [c_int32]),
-         "bff_profile_next_merge": (c_int32, [_P, _P]),
+         "bff_profile_next_merge": (c_int32, [_P, _P]), "bff_group_slice_cap": (c_int32, [c_int32, c_int32]),
+         "bff_scene_header_words": (c_int32, [c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
          "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
          "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}
@@ -96,12 +103,20 @@ def load():
     return lib
 
 
-_stream_cache = None      # (c_void_p, torch stream) pinned for the duration of a `with launch_stream():` block
+import threading
+
+_tls = threading.local()  # .cache = (c_void_p, torch stream) pinned for the duration of a `with launch_stream():` block
+                          # (per thread: loader threads of the ingestion pipeline launch on their own streams)
+
+
+def _cached_stream():
+    return getattr(_tls, "cache", None)
 
 
 def _stream():
-    if _stream_cache is not None:
-        return _stream_cache[0]
+    c = _cached_stream()
+    if c is not None:
+        return c[0]
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -111,15 +126,13 @@ class launch_stream:
     must not be switched inside the block."""
 
     def __enter__(self):
-        global _stream_cache
-        self._outer = _stream_cache
+        self._outer = _cached_stream()
         st = torch.cuda.current_stream()
-        _stream_cache = (c_void_p(st.cuda_stream), st)
+        _tls.cache = (c_void_p(st.cuda_stream), st)
         return self
 
     def __exit__(self, *exc):
-        global _stream_cache
-        _stream_cache = self._outer
+        _tls.cache = self._outer
         return False
 
 
@@ -213,7 +226,7 @@ class RowArena:
 
     @classmethod
     def for_current_stream(cls, device):
-        st = _stream_cache[1] if _stream_cache is not None else torch.cuda.current_stream(device)
+        st = _cached_stream()[1] if _cached_stream() is not None else torch.cuda.current_stream(device)
         key = (st.device.index, st.cuda_stream)
         a = cls._arenas.get(key)
         if a is None:
@@ -566,7 +579,7 @@ def fetch(*tensors):
         host.append((buf, t.shape))
     global sync_wait_s
     t0 = time.perf_counter()
-    (_stream_cache[1] if _stream_cache is not None else torch.cuda.current_stream()).synchronize()
+    (_cached_stream()[1] if _cached_stream() is not None else torch.cuda.current_stream()).synchronize()
     sync_wait_s += time.perf_counter() - t0
     return [b.numpy().reshape(shape).copy() for b, shape in host]
 

@@ -226,8 +226,10 @@ __global__ __launch_bounds__(256) void row_stats_sparse_kernel(const uint64_t *_
 // Undo what the sweep stored: zero exactly the chunks flagged in the rows' occupancy masks (one wave per row), so
 // that a zero-filled row arena is all zero again after a scene without touching its other 99 %.
 __global__ __launch_bounds__(256) void clear_flagged_chunks_kernel(uint64_t *__restrict__ rows, int n_rows, int64_t nw,
-                                                                    const uint64_t *__restrict__ cmask, int mw)
+                                                                    const uint64_t *__restrict__ cmask, int mw,
+                                                                    const int32_t *__restrict__ veto)
 {
+    if (veto && *veto) return;                     // the host still needs the rows (general path)
     const int lane = lane_id();
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
@@ -776,15 +778,18 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
     __syncthreads();
     if (kDiag) diag_lap(diag, 4, &t_lap);                                     // rows, roots, histogram staging
     // local sets start from the global forest: a live row joins the first live row of the tile pair with its root
-    if (tid < 2 * kT) {
+    if (tid < 2 * kT) {                            // waves 0 and 1; loops without early exit: the LDS reads pipeline
         const int mine = tid < kT ? rootA[tid] : rootB[tid - kT];
         int first = tid;
-        if (mine >= 0)
-            for (int q = 0; q < tid; ++q) {
-                const int other = q < kT ? rootA[q] : rootB[q - kT];
-                if (other == mine) { first = q; break; }
-            }
-        lid[tid] = first;
+#pragma unroll 16
+        for (int q = 0; q < kT; ++q)
+            if (rootA[q] == mine && q < first) first = q;
+        if (tid >= kT) {
+#pragma unroll 16
+            for (int q = 0; q < kT; ++q)
+                if (rootB[q] == mine && kT + q < first) first = kT + q;
+        }
+        lid[tid] = mine >= 0 ? first : tid;        // roots of rows that cannot have an edge are -1 / -2: sets of their own
     }
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     uint32_t ub[4][4];
@@ -1064,6 +1069,7 @@ __global__ void permute_bits_kernel(const uint64_t *__restrict__ in, int64_t nw_
 
 // ---- group OR / confidence mean ---------------------------------------------------------------
 constexpr int kOrSplit = 32;      // members per block along z
+constexpr int kFuseMax = 64;      // rows of the fused overlap pass = groups the device forms by itself
 
 // Sequential mean of one group's confidences by the first wave of the calling block: all its lanes gather
 // 1024 confidences into LDS at once (the gathers are the slow part), then lane 0 runs the strictly sequential
@@ -1134,6 +1140,134 @@ __global__ __launch_bounds__(64) void group_conf_mean_kernel(const T *__restrict
     group_conf_mean_wave(conf, offs, members, (int)blockIdx.x, mean, stage);
 }
 
+// ---- groups on the device -------------------------------------------------------------------------
+// Component ids -> the groups merge_masks keeps (P:203-226), without a host round trip: the device twin of
+// bff_host_component_csr for at most `cap` groups.  comp[i] = smallest row index of i's component, so group
+// order "by smallest member" is the order of the roots, and "members ascending" is the order of the rows.
+//   info[0] = K (number of kept groups, may exceed cap), info[1] = flags (1: K > cap, 2: empty components survive
+//   the filter, i.e. min_members <= 0 -- both mean "take the general host path"), info[2] = largest kept group,
+//   info[3] = number of 32-member slices of the kept groups (work items of bff_or_reduce_grouped).
+__global__ void group_count_kernel(const int32_t *__restrict__ comp, int n, int32_t *__restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(count + comp[i], 1);
+}
+
+__global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restrict__ comp, const int32_t *__restrict__ count,
+                                                           const int32_t *__restrict__ area, int n, float thr,
+                                                           int min_members, int cap, int32_t *__restrict__ info,
+                                                           int32_t *__restrict__ sizes, int32_t *__restrict__ first,
+                                                           int32_t *__restrict__ offs, int32_t *__restrict__ slices,
+                                                           int slice_cap)
+{
+    __shared__ int wsum[16];
+    __shared__ int s_base, s_void, s_max;
+    __shared__ int s_off[kFuseMax + 1], s_soff[kFuseMax + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_base = 0; s_void = 0; s_max = 0; }
+    __syncthreads();
+    const int need = min_members > 1 ? min_members : 1;
+    const bool loops = 1.0f > thr;                                  // a non-empty row is adjacent to itself iff 1 > thr
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int c = c0 + tid;
+        bool valid = false, is_void = false;
+        int sz = 0;
+        if (c < n && comp[c] == c) {
+            sz = count[c];
+            is_void = sz == 1 && !(area[c] > 0 && loops);           // isolated row without a self loop: the reference's []
+            valid = !is_void && sz >= need;
+        }
+        const uint64_t bal = __ballot(valid);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        if (is_void) atomicAdd(&s_void, 1);
+        __syncthreads();
+        int g = s_base + __popcll(bal & ((1ull << lane) - 1));
+        for (int q = 0; q < wave; ++q) g += wsum[q];
+        if (valid) {
+            if (g < cap) { sizes[g] = sz; first[g] = c; }
+            atomicMax(&s_max, sz);
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int q = 0; q < 16; ++q) t += wsum[q]; s_base += t; }
+        __syncthreads();
+    }
+    const int k_all = s_base, k = min(k_all, cap);
+    if (tid == 0) {
+        int o = 0, so = 0;
+        for (int g = 0; g < k; ++g) { s_off[g] = o; s_soff[g] = so; o += sizes[g]; so += (sizes[g] + kOrSplit - 1) / kOrSplit; }
+        s_off[k] = o; s_soff[k] = so;
+        info[0] = k_all;
+        info[1] = (k_all > cap ? 1 : 0) | ((min_members <= 0 && s_void > 0) ? 2 : 0);
+        info[2] = s_max;
+        info[3] = min(so, slice_cap);
+    }
+    __syncthreads();
+    for (int g = tid; g <= k; g += 1024) offs[g] = s_off[g];
+    for (int g = tid + k + 1; g <= cap; g += 1024) offs[g] = s_off[k];
+    // slice s of group g covers members [offs[g] + 32 j, min(offs[g+1], ...)): table rows (group, lo, hi)
+    const int n_slices = min(s_soff[k], slice_cap);
+    for (int sidx = tid; sidx < n_slices; sidx += 1024) {
+        int g = 0;
+        while (g + 1 < k && s_soff[g + 1] <= sidx) ++g;
+        const int lo = s_off[g] + (sidx - s_soff[g]) * kOrSplit;
+        slices[sidx] = g;
+        slices[slice_cap + sidx] = lo;
+        slices[2 * slice_cap + sidx] = min(s_off[g + 1], lo + kOrSplit);
+    }
+}
+
+// members of group g in ascending row order: one wave per group walks comp[] 64 rows at a time
+__global__ __launch_bounds__(256) void group_members_kernel(const int32_t *__restrict__ comp, int n,
+                                                             const int32_t *__restrict__ info, int cap,
+                                                             const int32_t *__restrict__ first,
+                                                             const int32_t *__restrict__ offs,
+                                                             int32_t *__restrict__ members)
+{
+    const int lane = lane_id();
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= min(info[0], cap)) return;
+    const int root = first[g];
+    int base = offs[g];
+    for (int i0 = 0; i0 < n; i0 += kWave) {
+        const int i = i0 + lane;
+        const bool m = i < n && comp[i] == root;
+        const uint64_t bal = __ballot(m);
+        if (m) members[base + __popcll(bal & ((1ull << lane) - 1))] = i;
+        base += __popcll(bal);
+    }
+}
+
+// bff_or_reduce_groups for groups formed on the device: the work items are the 32-member slices listed by
+// group_scan_kernel (their number is only known on the device: blocks beyond it leave at once); slice y = 0 of the
+// grid computes the sequential confidence means, as in or_reduce_groups_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void or_reduce_grouped_kernel(const uint64_t *__restrict__ rows, int64_t nw,
+                                                                 const int32_t *__restrict__ info, int cap,
+                                                                 const int32_t *__restrict__ offs,
+                                                                 const int32_t *__restrict__ members,
+                                                                 const int32_t *__restrict__ slices, int slice_cap,
+                                                                 uint64_t *__restrict__ out, const T *__restrict__ conf,
+                                                                 T *__restrict__ mean)
+{
+    __shared__ T stage[1024];
+    if (blockIdx.y == 0) {
+        if (conf && threadIdx.x < kWave) {
+            const int k = min(info[0], cap);
+            for (int q = blockIdx.x; q < k; q += gridDim.x) group_conf_mean_wave(conf, offs, members, q, mean, stage);
+        }
+        return;
+    }
+    const int sidx = (int)blockIdx.y - 1;
+    if (sidx >= info[3]) return;
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    const int g = slices[sidx], lo = slices[slice_cap + sidx], hi = slices[2 * slice_cap + sidx];
+    uint64_t v = 0;
+#pragma unroll 8
+    for (int m = lo; m < hi; ++m) v |= rows[(int64_t)members[m] * nw + w];
+    if (v) atomicOr((unsigned long long *)(out + (int64_t)g * nw + w), (unsigned long long)v);
+}
+
 // ---- row programs -----------------------------------------------------------------------------
 // Sequential overlap decisions of solve_overlapping (P:285-299) on the device: inter is the K x K
 // intersection matrix of the aggregated rows BEFORE any edit (P:289-292), size[i] the number of raw masks
@@ -1186,14 +1320,21 @@ __global__ void apply_row_ops_kernel(uint64_t *__restrict__ rows, int64_t nw, co
 // rows.  One wave per 64 word columns: the K words of a column live in LDS, every thread replays the reference's
 // ordered pair loop on its own column (the pair flags come from the intersections BEFORE any edit, P:289-292),
 // ANDs with `keep`, writes the column back and the wave adds the columns' popcounts to after[].
-constexpr int kFuseMax = 64;
 
 __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restrict__ rows, int64_t nw, int k,
-                                                              const int32_t *__restrict__ inter,
+                                                              const int32_t *__restrict__ inter, int stride,
                                                               const int32_t *__restrict__ size,
                                                               const uint64_t *__restrict__ keep,
-                                                              int32_t *__restrict__ before, int32_t *__restrict__ after)
+                                                              int32_t *__restrict__ before, int32_t *__restrict__ after,
+                                                              const int32_t *__restrict__ k_dev)
 {
+    // k_dev != NULL: the row count lives on the device (groups formed there); k is then the capacity the launch
+    // was sized for and a count beyond it leaves the rows alone (the host sees the count and takes the general path)
+    if (k_dev) {
+        const int kd = *k_dev;
+        if (kd <= 0 || kd > k) return;
+        k = kd;
+    }
     constexpr int kPitch = kWave + 1;                        // column- and row-wise LDS accesses both conflict-free
     __shared__ unsigned long long s_mask[kFuseMax];          // row i -> rows j > i that overlap it
     __shared__ int s_size[kFuseMax];
@@ -1204,7 +1345,7 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
     const int64_t w = (int64_t)blockIdx.x * kWave + t;
     // independent loads, several in flight: the intersections, then this thread's word of every row
 #pragma unroll 8
-    for (int q = t; q < k * k; q += kWave) s_int[q] = inter[q];
+    for (int q = t; q < k * k; q += kWave) s_int[q] = inter[(q / k) * stride + (q % k)];
 #pragma unroll 8
     for (int r = 0; r < k; ++r) s_col[r * kPitch + t] = w < nw ? rows[(int64_t)r * nw + w] : 0;
     if (t < k) s_size[t] = size[t];
@@ -1453,8 +1594,19 @@ extern "C" int bff_clear_flagged_chunks(uint64_t *rows, int32_t n_rows, int64_t 
     if (n_rows == 0 || nw == 0) return BFF_OK;
     BFF_REQUIRE(rows && chunk_mask, "bff_clear_flagged_chunks: null pointer");
     clear_flagged_chunks_kernel<<<(unsigned)ceil_div(n_rows, 4), 256, 0, as_stream(stream)>>>(
-        rows, n_rows, nw, chunk_mask, (int)ceil_div(ceil_div(nw, kCW), 64));
+        rows, n_rows, nw, chunk_mask, (int)ceil_div(ceil_div(nw, kCW), 64), nullptr);
     return launched("bff_clear_flagged_chunks");
+}
+
+extern "C" int bff_clear_flagged_chunks_unless(uint64_t *rows, int32_t n_rows, int64_t nw, const uint64_t *chunk_mask,
+                                               const int32_t *veto, void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_clear_flagged_chunks_unless: bad sizes");
+    if (n_rows == 0 || nw == 0) return BFF_OK;
+    BFF_REQUIRE(rows && chunk_mask && veto, "bff_clear_flagged_chunks_unless: null pointer");
+    clear_flagged_chunks_kernel<<<(unsigned)ceil_div(n_rows, 4), 256, 0, as_stream(stream)>>>(
+        rows, n_rows, nw, chunk_mask, (int)ceil_div(ceil_div(nw, kCW), 64), veto);
+    return launched("bff_clear_flagged_chunks_unless");
 }
 
 extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
@@ -1633,8 +1785,23 @@ extern "C" int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const
     if (e != hipSuccess) return fail((int)e, "bff_resolve_overlaps: memset: %s", hipGetErrorString(e));
     resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave,
                               sizeof(uint64_t) * (size_t)k * (kWave + 1) + sizeof(int32_t) * (size_t)k * k,
-                              as_stream(stream)>>>(rows, nw, k, inter, size, keep, before, after);
+                              as_stream(stream)>>>(rows, nw, k, inter, k, size, keep, before, after, nullptr);
     return launched("bff_resolve_overlaps");
+}
+
+extern "C" int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *inter,
+                                        const int32_t *size, const uint64_t *keep, int32_t *before, int32_t *after,
+                                        const int32_t *k_dev, void *stream)
+{
+    BFF_REQUIRE(k_cap > 0 && nw >= 0, "bff_resolve_overlaps_dev: bad sizes");
+    BFF_LIMIT(k_cap <= kFuseMax, "bff_resolve_overlaps_dev: capacity beyond %d rows", kFuseMax);
+    BFF_REQUIRE(rows && inter && size && before && after && k_dev, "bff_resolve_overlaps_dev: null pointer");
+    hipError_t e = hipMemsetAsync(after, 0, sizeof(int32_t) * (size_t)k_cap, as_stream(stream));
+    if (e != hipSuccess) return fail((int)e, "bff_resolve_overlaps_dev: memset: %s", hipGetErrorString(e));
+    resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave,
+                              sizeof(uint64_t) * (size_t)k_cap * (kWave + 1) + sizeof(int32_t) * (size_t)k_cap * k_cap,
+                              as_stream(stream)>>>(rows, nw, k_cap, inter, k_cap, size, keep, before, after, k_dev);
+    return launched("bff_resolve_overlaps_dev");
 }
 
 extern "C" int bff_resolve_overlaps_max_rows(void) { return kFuseMax; }
@@ -1732,4 +1899,52 @@ extern "C" int bff_ids_to_rows(const int64_t *ids, int64_t n_points, const int64
     dim3 grid((unsigned)ceil_div(nw * 64, 256), (unsigned)n_values);
     ids_to_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(ids, n_points, values, nw, rows);
     return launched("bff_ids_to_rows");
+}
+
+extern "C" int32_t bff_group_slice_cap(int32_t n_rows, int32_t cap) { return n_rows / kOrSplit + cap + 1; }
+
+extern "C" int bff_group_components(const int32_t *comp, const int32_t *area, int32_t n_rows, float iou_thres,
+                                    int32_t min_members, int32_t cap, int32_t *count, int32_t *info, int32_t *sizes,
+                                    int32_t *first, int32_t *offs, int32_t *members, int32_t *slices, void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && cap > 0, "bff_group_components: bad sizes");
+    BFF_LIMIT(cap <= kFuseMax, "bff_group_components: at most %d groups on the device", kFuseMax);
+    BFF_REQUIRE(info && sizes && first && offs && slices && (n_rows == 0 || (comp && area && count && members)),
+                "bff_group_components: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (n_rows > 0) {
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t) * (size_t)n_rows, st);
+        if (e != hipSuccess) return fail((int)e, "bff_group_components: memset: %s", hipGetErrorString(e));
+        group_count_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(comp, n_rows, count);
+    }
+    group_scan_kernel<<<1, 1024, 0, st>>>(comp, count, area, n_rows, iou_thres, min_members, cap, info, sizes, first, offs,
+                                         slices, bff_group_slice_cap(n_rows, cap));
+    if (n_rows > 0)
+        group_members_kernel<<<(unsigned)ceil_div(cap, 4), 256, 0, st>>>(comp, n_rows, info, cap, first, offs, members);
+    return launched("bff_group_components");
+}
+
+extern "C" int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n_rows, const int32_t *info, int32_t cap,
+                                     const int32_t *offs, const int32_t *members, const int32_t *slices, uint64_t *out,
+                                     const void *conf, int32_t conf_dtype, void *conf_mean, void *stream)
+{
+    BFF_REQUIRE(nw >= 0 && n_rows >= 0 && cap > 0, "bff_or_reduce_grouped: bad sizes");
+    BFF_REQUIRE(rows && info && offs && members && slices && out, "bff_or_reduce_grouped: null pointer");
+    BFF_REQUIRE((conf == nullptr) == (conf_mean == nullptr) && (conf_dtype == 0 || conf_dtype == 1),
+                "bff_or_reduce_grouped: conf and conf_mean go together, dtype 0 (f32) or 1 (f16)");
+    hipStream_t st = as_stream(stream);
+    if (nw > 0) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t) * (size_t)cap * nw, st);
+        if (e != hipSuccess) return fail((int)e, "bff_or_reduce_grouped: memset: %s", hipGetErrorString(e));
+    }
+    const int slice_cap = bff_group_slice_cap(n_rows, cap);
+    dim3 grid((unsigned)ceil_div(nw > 0 ? nw : 1, 256), (unsigned)(slice_cap + 1));
+    BFF_LIMIT(slice_cap + 1 <= 65535, "bff_or_reduce_grouped: too many member slices");
+    if (conf_dtype == 1)
+        or_reduce_grouped_kernel<__half><<<grid, 256, 0, st>>>(rows, nw, info, cap, offs, members, slices, slice_cap, out,
+                                                              (const __half *)conf, (__half *)conf_mean);
+    else
+        or_reduce_grouped_kernel<float><<<grid, 256, 0, st>>>(rows, nw, info, cap, offs, members, slices, slice_cap, out,
+                                                             (const float *)conf, (float *)conf_mean);
+    return launched("bff_or_reduce_grouped");
 }

@@ -1,0 +1,134 @@
+// One scene, one call: every device step of tools/projection_2d_to_3d.py:402-634 (+ the first device pass of
+// tools/refinement.py:186-217) issued on one stream without a single host dependency, results in ONE pinned
+// read-back.  The host thread spends one native call per scene instead of ~45 Python-issued launches and two
+// stream synchronisations; everything here is a sequence of the library's own entry points (include/bff_hip.h),
+// so each step keeps its contract and its tests.
+//
+//   decode -> sweep -> point filter threshold -> keep bits -> row statistics -> tile order -> components ->
+//   groups (device) -> OR of members + confidence means -> (rows recycled) -> overlaps + filter + counts ->
+//   caller point order -> stage-1 decode -> stage-1 x (stage-2 | stage-1) intersections -> header to the host
+#include "common.h"
+
+using namespace bff;
+
+namespace {
+
+__global__ void order_keys_kernel(const int64_t *__restrict__ sig, const int32_t *__restrict__ label_id, int n,
+                                  int sig_bits, int64_t *__restrict__ keys)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = ((int64_t)label_id[i] << sig_bits) | sig[i];     // stable sort by (label, signature)
+}
+
+int bits_for(int n)
+{
+    int b = 1;
+    while ((1 << b) < n && b < 31) ++b;
+    return b;
+}
+
+}  // namespace
+
+#define BFF_TRY(call) do { const int rc_ = (call); if (rc_ != BFF_OK) return rc_; } while (0)
+
+extern "C" int32_t bff_scene_header_words(int32_t s1_rows)
+{
+    return BFF_HDR_CROSS + s1_rows * (BFF_GROUP_CAP + s1_rows);
+}
+
+extern "C" int32_t bff_scene_struct_bytes(int32_t which)
+{
+    return which == 0 ? (int32_t)sizeof(bff_scene) : which == 1 ? (int32_t)sizeof(bff_scene_params)
+                                                                 : (int32_t)sizeof(bff_scene_workspace);
+}
+
+extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr, const bff_scene_workspace *ws,
+                                 void *stream)
+{
+    BFF_REQUIRE(sc && pr && ws, "bff_scene_project: null struct");
+    BFF_REQUIRE(sc->n_points > 0 && sc->n_rows > 0 && sc->n_mviews > 0 && sc->n_frames > 0,
+                "bff_scene_project: empty scenes take the general path");
+    BFF_REQUIRE(ws->hdr && ws->hdr_host, "bff_scene_project: no header buffers");
+    hipStream_t st = as_stream(stream);
+    const int64_t n = sc->n_points, nw = sc->nw, hw = (int64_t)sc->height * sc->width;
+    const int n_rows = sc->n_rows, cap = BFF_GROUP_CAP;
+    const int mw = bff_chunk_mask_words(nw);
+    int32_t *hdr = ws->hdr;
+    hipError_t e;
+#define BFF_ZERO(ptr, bytes) do { e = hipMemsetAsync((ptr), 0, (bytes), st); \
+        if (e != hipSuccess) return fail((int)e, "bff_scene_project: memset: %s", hipGetErrorString(e)); } while (0)
+
+    // a1: 2-D RLE -> mask words (+ segment bitmap)
+    BFF_TRY(bff_rle_to_maskbits(sc->run_start, sc->run_end, sc->mask_run_offs, sc->view_mask_offs, sc->n_mviews, hw,
+                                sc->word_bits, ws->maskbits, ws->segmap, stream));
+    // a2-a8 (+a15): the fused sweep.  ws->rows is all zero on entry (and again on exit, see below)
+    BFF_ZERO(ws->masked, sizeof(int32_t) * (size_t)n);
+    const bool ratio = pr->filter_mode == 2;
+    if (ratio) BFF_ZERO(ws->viewed, sizeof(int32_t) * (size_t)n);
+    BFF_ZERO(ws->chunk_mask, sizeof(uint64_t) * (size_t)n_rows * mw);
+    BFF_ZERO(hdr, sizeof(int32_t) * BFF_HDR_SIZES);
+    BFF_TRY(bff_project_views(sc->xyz, n, sc->n_pad, sc->inv_pose, sc->cam_intr, sc->n_frames, sc->depth, sc->depth_index,
+                              sc->height, sc->width, pr->depth_thresh, ws->maskbits, ws->segmap, sc->word_bits,
+                              sc->frame_mask, sc->frame_rowbase, sc->frame_nmask, sc->frame_flags, ws->rows, n_rows, nw,
+                              ws->chunk_mask, ws->masked, ratio ? ws->viewed : nullptr, sc->tile_bounds, stream));
+    // a14 / a15: point filter, threshold stays on the device (header words 2, 3 = n_unique, thr)
+    if (pr->filter_mode != 0) {
+        BFF_TRY(bff_point_values(ws->masked, ratio ? ws->viewed : nullptr, n, ws->vals, stream));
+        size_t tb = ws->sort_temp_bytes;
+        BFF_TRY(bff_sort_f32(ws->vals, ws->vals_sorted, n, ws->sort_temp, &tb, stream));
+        BFF_TRY(bff_select_unique_rank(ws->vals_sorted, n, pr->filter_fraction, ws->sel_scratch,
+                                       reinterpret_cast<float *>(hdr + BFF_HDR_THR), hdr + BFF_HDR_NUNIQUE, stream));
+        BFF_TRY(bff_ratio_keep(ws->masked, ratio ? ws->viewed : nullptr, n, 0.0f,
+                               reinterpret_cast<const float *>(hdr + BFF_HDR_THR), 1, nw, ws->keep, stream));
+    } else {
+        BFF_TRY(bff_ratio_keep(ws->masked, nullptr, n, 0.0f, nullptr, 0, nw, ws->keep, stream));
+    }
+    // a9-a12: statistics through the chunk flags, tile order (label, signature), components
+    BFF_TRY(bff_row_stats(ws->rows, n_rows, nw, ws->area, ws->mean_word, ws->chunk_mask, 1, ws->hist, ws->sig, stream));
+    {
+        const int64_t *keys = ws->sig;
+        int key_bits = BFF_SIGNATURE_BITS;
+        if (sc->n_label_ids > 1) {
+            key_bits += bits_for(sc->n_label_ids);
+            order_keys_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(ws->sig, sc->label_id, n_rows,
+                                                                              BFF_SIGNATURE_BITS, ws->sig_keys);
+            keys = ws->sig_keys;
+        }
+        size_t tb = ws->sort_temp_bytes;
+        BFF_TRY(bff_argsort_i64(keys, ws->sig_sorted, ws->order, n_rows, key_bits, ws->sort_temp, &tb, stream));
+    }
+    BFF_TRY(bff_merge_components(ws->rows, n_rows, nw, ws->order, n_rows, ws->chunk_mask, ws->tile_mask, ws->hist,
+                                 ws->merge_scratch, ws->area, sc->label_id, pr->iou_thres, ws->parent, 1, ws->comp, nullptr,
+                                 stream));
+    // P:203-226 on the device: groups, OR of the members, sequential confidence means
+    int32_t *info = hdr + BFF_HDR_K;
+    BFF_TRY(bff_group_components(ws->comp, ws->area, n_rows, pr->iou_thres, pr->min_members, cap, ws->count, info,
+                                 hdr + BFF_HDR_SIZES, hdr + BFF_HDR_FIRST, ws->goffs, ws->gmembers, ws->slices, stream));
+    BFF_TRY(bff_or_reduce_grouped(ws->rows, nw, n_rows, info, cap, ws->goffs, ws->gmembers, ws->slices, ws->agg, sc->conf,
+                                  sc->conf_f16, hdr + BFF_HDR_CONF, stream));
+    // last reader of the raw rows is done: give the arena its zeros back -- unless the host has to take the general
+    // path (more groups than the device forms), which reads the rows again and clears them itself
+    BFF_TRY(bff_clear_flagged_chunks_unless(ws->rows, n_rows, nw, ws->chunk_mask, info + 1, stream));
+    // a16 + P:592-596: intersections before any edit, ordered overlap decisions, &= keep, both popcounts
+    BFF_TRY(bff_cross_popcount(ws->agg, nullptr, cap, ws->agg, nullptr, cap, nw, ws->inter, stream));
+    BFF_TRY(bff_resolve_overlaps_dev(ws->agg, cap, nw, ws->inter, hdr + BFF_HDR_SIZES, ws->keep, hdr + BFF_HDR_BEFORE,
+                                     hdr + BFF_HDR_AFTER, info, stream));
+    // caller's point order; the refinement's first device pass (R:186-217) rides along when stage 1 is resident
+    if (sc->unsort) {
+        BFF_TRY(bff_permute_bits(ws->agg, cap, nw, sc->unsort, n, nw, ws->both, stream));
+    } else {
+        e = hipMemcpyAsync(ws->both, ws->agg, sizeof(uint64_t) * (size_t)cap * nw, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return fail((int)e, "bff_scene_project: copy: %s", hipGetErrorString(e));
+    }
+    if (sc->s1_rows > 0) {
+        uint64_t *s1 = ws->both + (size_t)cap * nw;
+        BFF_TRY(bff_rle_to_rows(sc->s1_run_start, sc->s1_run_end, sc->s1_row_run_offs, sc->s1_rows, n, nw, s1, stream));
+        BFF_TRY(bff_cross_popcount(s1, nullptr, sc->s1_rows, ws->both, nullptr, cap + sc->s1_rows, nw,
+                                   hdr + BFF_HDR_CROSS, stream));
+    }
+    e = hipMemcpyAsync(ws->hdr_host, hdr, sizeof(int32_t) * (size_t)bff_scene_header_words(sc->s1_rows),
+                       hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return fail((int)e, "bff_scene_project: header copy: %s", hipGetErrorString(e));
+    return BFF_OK;
+#undef BFF_ZERO
+}

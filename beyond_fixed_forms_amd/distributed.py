@@ -148,77 +148,114 @@ class PaddedRows:
         return self.rows().tolist()
 
 
+_CONF_CODES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
+
+
+def pack_class_results(local, scene_index, s_max, device):
+    """{scene_id: (rows int64 [R][nw] | None, conf tensor | [], final_class)} of this rank -> ONE int64 matrix
+    [s_max + sum R][nw_max + 1] for a single gather: first s_max descriptor rows (global scene index, R, nw,
+    saved-as-lists flag, confidence dtype code; unused ones hold -1), then the bit rows of all scenes, each with its
+    confidence (float64 bits) in the extra last column.  final_class needs no transport: every row carries the
+    query (R:343, 390)."""
+    nw_max = max([r.shape[1] for r, _, _ in local.values() if r is not None] + [4])     # >= 5 columns for the descriptors
+    total = sum(0 if r is None else r.shape[0] for r, _, _ in local.values())
+    out = torch.zeros((s_max + total, nw_max + 1), dtype=torch.int64, device=device)
+    desc = torch.full((s_max, 5), -1, dtype=torch.int64)
+    at = s_max
+    for k, (sid, (rows, conf, _cls)) in enumerate(local.items()):
+        r = 0 if rows is None else rows.shape[0]
+        code = 0
+        if rows is not None and torch.is_tensor(conf):
+            code = _CONF_CODES[conf.dtype]
+        if r:
+            out[at:at + r, :rows.shape[1]] = rows
+            out[at:at + r, nw_max] = torch.as_tensor(conf).to(torch.float64).view(torch.int64).to(device)
+        desc[k] = torch.tensor([scene_index[sid], r, 0 if rows is None else rows.shape[1], 1 if rows is None else 0, code])
+        at += r
+    out[:s_max, :5] = desc.to(device)
+    return out
+
+
+def unpack_class_results(mat, scene_ids, s_max, text_prompt):
+    """Inverse of pack_class_results for one rank's matrix (host or device tensor)."""
+    mat = mat.cpu()
+    nw_max = mat.shape[1] - 1
+    out, at = {}, s_max
+    dtypes = {v: k for k, v in _CONF_CODES.items()}
+    for k in range(s_max):
+        idx, r, nw, is_list, code = (int(v) for v in mat[k, :5])
+        if idx < 0:
+            continue
+        if is_list:
+            out[scene_ids[idx]] = (None, [], [])
+            continue
+        rows = mat[at:at + r, :nw].contiguous()
+        conf = mat[at:at + r, nw_max].contiguous().view(torch.float64).to(dtypes[code])
+        out[scene_ids[idx]] = (rows, conf, [text_prompt] * r)
+        at += r
+    return out
+
+
 def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[float] = None):
     """One query class over many scenes on all ranks (the multi-GPU form of running
     tools/projection_2d_to_3d.py + tools/refinement.py for that class).
 
     scenes: list of SceneInputs-like objects (same list on every rank; only the rank's shard is touched).
-    Rank r projects and refines the scenes `shard_scenes` gives it; the similarity sets are pooled across
-    ranks before the threshold is taken (refinement.py:316-324), so every rank applies the threshold the
-    single-process class loop would.  Returns, on rank 0, {scene_id: (rows int64 [R][nw] or None, conf,
-    final_class)} for ALL scenes (bit rows gathered over RCCL, small metadata over the object channel);
-    on the other ranks the dict of their own shard."""
+    Rank r projects and refines the scenes `shard_scenes` gives it.  Two collectives, the same two `bench.py
+    --gpus N` times: ONE all-gather (ClassExchange: every rank's similarity set -- the threshold is a percentile
+    over the set of all scenes' similarities, refinement.py:316-324 -- and its bound on the rows it will deliver)
+    and ONE gather of equally padded result matrices (bit rows + confidences + a few descriptor rows;
+    pack_class_results).  No object collectives, no size exchange; the gathered header is read after the loop.
+    Returns, on rank 0, {scene_id: (rows int64 [R][nw] or None, conf, final_class)} for ALL scenes; on the other
+    ranks the dict of their own shard."""
     from .projection import projection_back, projection_front
     from .refinement import prepare_stage1, refine_class
     from .scene import prepare_scene
     rank, ws = world()
-    mine = shard_scenes([s.scene_id for s in scenes], weights=weights)
-    # two-stage software pipeline over two HIP streams: the GPU-only front half of scene k+1 (decode, sweep,
-    # components) is issued before the host finishes the back half of scene k
-    streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)] if torch.device(device).type == "cuda" else None
+    ids = [s.scene_id for s in scenes]
+    mine = shard_scenes(ids, weights=weights)
+    s_max = max(1, -(-len(scenes) // ws))                  # most scenes any rank owns
+    with_viewed = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
+    # software pipeline over two HIP streams: the device work of scene k+1 is issued before the host finishes scene k
+    on_gpu = torch.device(device).type == "cuda"
+    streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)] if on_gpu else None
 
     def front(k):
-        ds = prepare_scene(scenes[mine[k]], cfg, device=device,
-                           with_viewed=(not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold))
+        sc = scenes[mine[k]]
+        ds = prepare_scene(sc, cfg, device=device, with_viewed=with_viewed)
+        st1 = prepare_stage1(sc.stage1, device)
         if streams is None:
-            return projection_front(ds, cfg)
-        streams[k % 2].wait_stream(torch.cuda.current_stream())       # the upload ran on the current stream
+            return projection_front(ds, cfg, stage1=st1), st1
+        streams[k % 2].wait_stream(torch.cuda.current_stream())       # the uploads ran on the current stream
         with torch.cuda.stream(streams[k % 2]):
-            return projection_front(ds, cfg)
+            return projection_front(ds, cfg, stage1=st1), st1
 
-    def back(k, fr, st1):
+    def back(k, fr):
         if streams is None:
-            return projection_back(fr, stage1=st1)
+            return projection_back(fr)
         with torch.cuda.stream(streams[k % 2]):
-            res = projection_back(fr, stage1=st1)
+            res = projection_back(fr)
         torch.cuda.current_stream().wait_stream(streams[k % 2])       # results are used on the current stream
         return res
 
     trip = []
     nxt = front(0) if mine else None
     for k, i in enumerate(mine):
-        cur = nxt
+        cur, st1 = nxt
         if k + 1 < len(mine):
             nxt = front(k + 1)
-        st1 = prepare_stage1(scenes[i].stage1, device)
-        trip.append((scenes[i].scene_id, st1, back(k, cur, st1)))
-    exchange = (lambda sims: exchange_similarities(sims, device=device)) if ws > 1 else None
+        trip.append((scenes[i].scene_id, st1, back(k, cur)))
+    exchange = ClassExchange(device) if ws > 1 else None
     final = refine_class(trip, cfg, text_prompt, sim, device, exchange_sims=exchange) if trip or ws > 1 else {}
     local = {sid: (r.rows, r.conf, list(r.final_class)) for sid, r in final.items()}
     if ws == 1:
         return local
-    # rows of all local scenes stacked into one [sum R][nw_max] buffer -> one gather; metadata as objects
-    nw_max = max([r.shape[1] for r, _, _ in local.values() if r is not None] + [1])
-    parts, meta = [], []
-    for sid, (rows, conf, cls) in local.items():
-        k = 0 if rows is None else rows.shape[0]
-        if k:
-            pad = torch.zeros((k, nw_max), dtype=torch.int64, device=device)
-            pad[:, :rows.shape[1]] = rows
-            parts.append(pad)
-        meta.append((sid, k, None if rows is None else rows.shape[1],
-                     conf if isinstance(conf, list) else conf.cpu(), cls, rows is None))
-    stacked = torch.cat(parts) if parts else torch.zeros((0, nw_max), dtype=torch.int64, device=device)
-    gathered = gather_final_rows(stacked)
-    metas = [None] * ws
-    dist.all_gather_object(metas, meta)
+    mat = pack_class_results(local, {sid: i for i, sid in enumerate(ids)}, s_max, device)
+    r_max, w_max = exchange.bounds
+    gathered = gather_final_rows(mat, bounds=(s_max + r_max, max(w_max, 4) + 1))
     if rank != 0:
         return local
     out = {}
-    for r in range(ws):
-        at = 0
-        for sid, k, nw, conf, cls, is_list in metas[r]:
-            rows = None if is_list else gathered[r][at:at + k, :nw].contiguous()
-            at += k
-            out[sid] = (rows, conf, cls)
+    for g in gathered:                                      # the header is read here, after the loop
+        out.update(unpack_class_results(g.rows(), ids, s_max, text_prompt))
     return out

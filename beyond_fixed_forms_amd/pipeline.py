@@ -1,0 +1,225 @@
+"""One native call per scene: ctypes mirrors of bff_scene / bff_scene_params / bff_scene_workspace
+(include/bff_hip.h) and the scratch they point to.
+
+`bff_scene_project` issues every device step of the projection stage (P:402-634) and the refinement's first device
+pass (R:186-217) on one stream and ends with an asynchronous copy of a small header into pinned host memory.  The
+host thread's share of a scene is then: fill nothing (the structs are cached per scene), one call, and -- after the
+stream has caught up -- a few NumPy lines over the header (`projection._fast_back`)."""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+
+GROUP_CAP = 64
+HDR_K, HDR_NUNIQUE, HDR_THR = 0, 4, 5
+HDR_SIZES, HDR_FIRST, HDR_BEFORE, HDR_AFTER, HDR_CONF, HDR_CROSS = 16, 80, 144, 208, 272, 336
+
+
+class SceneStruct(ctypes.Structure):
+    _fields_ = [("n_points", c_int64), ("n_pad", c_int64), ("nw", c_int64),
+                ("xyz", c_void_p), ("tile_bounds", c_void_p), ("inv_pose", c_void_p), ("cam_intr", c_double * 9),
+                ("depth", c_void_p),
+                ("depth_index", c_void_p), ("frame_mask", c_void_p), ("frame_rowbase", c_void_p),
+                ("frame_nmask", c_void_p), ("frame_flags", c_void_p),
+                ("run_start", c_void_p), ("run_end", c_void_p), ("mask_run_offs", c_void_p), ("view_mask_offs", c_void_p),
+                ("conf", c_void_p), ("label_id", c_void_p), ("unsort", c_void_p),
+                ("s1_run_start", c_void_p), ("s1_run_end", c_void_p), ("s1_row_run_offs", c_void_p),
+                ("height", c_int32), ("width", c_int32), ("n_frames", c_int32), ("n_mviews", c_int32),
+                ("word_bits", c_int32), ("n_rows", c_int32), ("conf_f16", c_int32), ("n_label_ids", c_int32),
+                ("s1_rows", c_int32), ("pad_", c_int32)]
+
+
+class ParamsStruct(ctypes.Structure):
+    _fields_ = [("depth_thresh", c_double), ("filter_fraction", c_double), ("iou_thres", c_float),
+                ("min_members", c_int32), ("filter_mode", c_int32), ("pad_", c_int32)]
+
+
+_WS_PTRS = ["maskbits", "segmap", "rows", "chunk_mask", "keep", "tile_mask", "agg", "both",
+            "masked", "viewed", "sel_scratch", "area", "mean_word", "order", "parent", "comp", "count",
+            "gmembers", "goffs", "slices", "inter", "vals", "vals_sorted", "hist", "merge_scratch",
+            "sig", "sig_keys", "sig_sorted", "sort_temp"]
+
+
+class WorkspaceStruct(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in _WS_PTRS] + [("sort_temp_bytes", c_size_t), ("hdr", c_void_p), ("hdr_host", c_void_p)]
+
+
+_checked = False
+
+
+def _check_layout():
+    global _checked
+    if _checked:
+        return
+    lib = _lib.load()
+    for which, cls in enumerate((SceneStruct, ParamsStruct, WorkspaceStruct)):
+        if lib.bff_scene_struct_bytes(which) != ctypes.sizeof(cls):
+            raise _lib.BffLibraryError(f"{cls.__name__}: {ctypes.sizeof(cls)} bytes here, "
+                                       f"{lib.bff_scene_struct_bytes(which)} in libbff_hip.so (rebuild)")
+    _checked = True
+
+
+def _p(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def scene_struct(ds, stage1=None, n_frames=None):
+    """bff_scene of an uploaded scene (+ optionally its resident stage-1 run tables).  The struct only holds
+    pointers: `ds` / `stage1` must stay alive while it is used (callers keep it next to them)."""
+    _check_layout()
+    s = SceneStruct()
+    s.n_points, s.n_pad, s.nw = ds.n_points, ds.xyz.shape[1], ds.nw
+    s.xyz, s.tile_bounds, s.inv_pose = _p(ds.xyz), _p(ds.tile_bounds), _p(ds.inv_pose)
+    s.cam_intr = (c_double * 9)(*[float(v) for v in np.asarray(ds.cam_intr).reshape(-1)])
+    s.depth = _p(ds.depth)
+    for k in ("depth_index", "frame_mask", "frame_rowbase", "frame_nmask", "frame_flags", "run_start", "run_end",
+              "mask_run_offs", "view_mask_offs", "label_id"):
+        setattr(s, k, _p(getattr(ds, k)))
+    s.conf, s.unsort = _p(ds.conf), _p(ds.unsort)
+    s.height, s.width = ds.height, ds.width
+    s.n_frames = ds.n_frames if n_frames is None else n_frames
+    s.n_mviews = ds.view_mask_offs.shape[0] - 1
+    s.word_bits, s.n_rows = ds.word_bits, ds.n_rows
+    s.conf_f16 = 1 if ds.conf.dtype == torch.float16 else 0
+    s.n_label_ids = ds.n_label_ids
+    if stage1 is not None:
+        s.s1_run_start, s.s1_run_end, s.s1_row_run_offs = _p(stage1.run_start), _p(stage1.run_end), _p(stage1.row_run_offs)
+        s.s1_rows = stage1.row_run_offs.shape[0] - 1
+    return s
+
+
+def params_struct(cfg, depth_thresh):
+    _check_layout()
+    p = ParamsStruct()
+    ratio = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
+    p.depth_thresh = float(depth_thresh)
+    p.filter_mode = 1 if cfg.if_occurance_threshold else (2 if ratio else 0)
+    p.filter_fraction = float(cfg.detected_ratio_threshold if ratio else cfg.occurance_threshold)
+    p.iou_thres = float(cfg.iou_thres)
+    p.min_members = int(cfg.min_aggragated_masks)
+    return p
+
+
+class SceneWorkspace:
+    """Scratch of bff_scene_project for one stream, grown on demand and reused scene after scene.  `rows` is the
+    zero arena of the instance rows: all zero whenever no call is in flight (the call clears what its sweep
+    stored; a call whose results were never collected leaves it marked dirty and it is zeroed again)."""
+    _per_stream = {}
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.t = {}                      # name -> tensor
+        self.cap = {}                    # name -> elements
+        self.struct = WorkspaceStruct()
+        self.hdr_host = None
+        self.in_flight = False
+        self.rows_dirty = False
+
+    @classmethod
+    def for_current_stream(cls, device):
+        st = torch.cuda.current_stream(device)
+        key = (st.device.index, st.cuda_stream)
+        ws = cls._per_stream.get(key)
+        if ws is None:
+            ws = cls._per_stream[key] = cls(st.device)
+        return ws
+
+    def _need(self, name, numel, dtype, zero=False):
+        t = self.t.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(max(int(numel), 1), dtype=dtype, device=self.device)
+            self.t[name] = t
+            setattr(self.struct, name, c_void_p(t.data_ptr()))
+            return True
+        return False
+
+    def fit(self, ds, s1_rows):
+        """Make every buffer large enough for scene `ds` (+ s1_rows stage-1 masks)."""
+        lib = _lib.load()
+        n, nw, n_rows = ds.n_points, ds.nw, ds.n_rows
+        hw = ds.height * ds.width
+        n_mviews = ds.view_mask_offs.shape[0] - 1
+        mw = max(lib.bff_chunk_mask_words(nw), 1)
+        nt = (n_rows + 63) // 64
+        i32, i64, f32 = torch.int32, torch.int64, torch.float32
+        self._need("maskbits", n_mviews * hw * (1 if ds.word_bits == 32 else 2), i32)
+        self._need("segmap", n_mviews * _lib.segmap_words(hw), i32)
+        if self._need("rows", n_rows * nw, i64, zero=True):
+            self.rows_dirty = False
+        self._need("chunk_mask", n_rows * mw, i64)
+        self._need("keep", nw, i64)
+        self._need("tile_mask", nt * mw, i64)
+        self._need("agg", GROUP_CAP * nw, i64)
+        for k in ("masked", "viewed"):
+            self._need(k, n, i32)
+        self._need("sel_scratch", (n + 1023) // 1024, i32)
+        for k in ("area", "mean_word", "order", "parent", "comp", "count", "gmembers"):
+            self._need(k, n_rows, i32)
+        self._need("goffs", GROUP_CAP + 1, i32)
+        self._need("slices", 3 * lib.bff_group_slice_cap(n_rows, GROUP_CAP), i32)
+        self._need("inter", GROUP_CAP * GROUP_CAP, i32)
+        self._need("vals", n, f32)
+        self._need("vals_sorted", n, f32)
+        self._need("hist", n_rows * 64, i32)
+        self._need("merge_scratch", int(lib.bff_merge_scratch_words(n_rows)), i32)
+        for k in ("sig", "sig_keys", "sig_sorted"):
+            self._need(k, n_rows, i64)
+        # both library sorts share one temp buffer
+        need = ctypes.c_size_t(0)
+        _lib.call("bff_sort_f32", None, None, n, None, ctypes.byref(need))
+        nb = int(need.value)
+        _lib.call("bff_argsort_i64", None, None, None, n_rows, 62, None, ctypes.byref(need))
+        nb = max(nb, int(need.value))
+        self._need("sort_temp", nb, torch.uint8)
+        self.struct.sort_temp_bytes = self.t["sort_temp"].numel()
+        words = int(lib.bff_scene_header_words(s1_rows))
+        if self._need("hdr", words, i32) or self.hdr_host is None or self.hdr_host.numel() < words:
+            self.hdr_host = torch.empty(self.t["hdr"].numel(), dtype=i32, pin_memory=True)
+            self.struct.hdr_host = c_void_p(self.hdr_host.data_ptr())
+        return self
+
+    def view(self, name, *shape):
+        n = int(np.prod(shape))
+        return self.t[name][:n].view(*shape)
+
+
+def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
+    """Enqueue the whole device side of one scene on the current stream.  Returns a handle for `collect`."""
+    dev = ds.xyz.device
+    key = (id(stage1), n_frames)
+    cache = ds.__dict__.setdefault("_scene_structs", {})
+    ent = cache.get(key)
+    if ent is None:
+        ent = cache[key] = (scene_struct(ds, stage1, n_frames), stage1)      # keeps stage1's tensors alive too
+    sc = ent[0]
+    s1_rows = int(sc.s1_rows)
+    ws = SceneWorkspace.for_current_stream(dev).fit(ds, s1_rows)
+    if ws.in_flight or ws.rows_dirty:             # a call whose results were never collected: the arena may be dirty
+        ws.t["rows"].zero_()
+        ws.rows_dirty = False
+    both = torch.empty((GROUP_CAP + s1_rows, ds.nw), dtype=torch.int64, device=dev)     # outlives the workspace's reuse
+    ws.struct.both = c_void_p(both.data_ptr())
+    pr = params_struct(cfg, depth_thresh)
+    ws.in_flight = True
+    _lib.call("bff_scene_project", ctypes.byref(sc), ctypes.byref(pr), ctypes.byref(ws.struct))
+    return dict(ws=ws, both=both, s1_rows=s1_rows, params=pr, stream=torch.cuda.current_stream(dev))
+
+
+def collect(h):
+    """Wait for the header of `issue` and return it as an int32 array (a copy: the pinned buffer is reused)."""
+    import time
+    t0 = time.perf_counter()
+    h["stream"].synchronize()
+    _lib.sync_wait_s += time.perf_counter() - t0
+    ws = h["ws"]
+    words = HDR_CROSS + h["s1_rows"] * (GROUP_CAP + h["s1_rows"])
+    hdr = ws.hdr_host.numpy()[:words].copy()
+    ws.in_flight = False
+    if hdr[HDR_K + 1] != 0:
+        ws.rows_dirty = True                      # the general path reads the rows and clears them itself
+    return hdr

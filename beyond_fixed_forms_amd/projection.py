@@ -14,9 +14,11 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from . import _lib
+import os
+
+from . import _lib, pipeline
 from .scene import DEPTH_THRESH, DeviceScene, prepare_scene
-from .timing import span, sweep_span
+from .timing import merge_span, span, sweep_span
 
 
 @dataclasses.dataclass
@@ -58,17 +60,24 @@ class _LazyGroups(list):
     """The reference's mask_indeces_to_be_merged (list of lists), materialised from CSR on first use --
     building ~10^4 Python ints per scene is not needed on the hot path."""
 
-    def __init__(self, offs, members):
+    def __init__(self, offs, members, fetch=None):
         super().__init__()
         self._csr = (offs, members)
+        self._dev = fetch                     # (offs, members) device tensors, read back on first use
 
     def _fill(self):
+        if self._dev is not None:
+            offs, members = self._dev
+            self._dev = None
+            self._csr = (offs.cpu().numpy(), members.cpu().numpy())
         if self._csr is not None:
             offs, members = self._csr
             self._csr = None
             super().extend(members[offs[g]:offs[g + 1]].tolist() for g in range(len(offs) - 1))
 
     def __len__(self):
+        if self._dev is not None:
+            return self._dev[0].shape[0] - 1
         return len(self._csr[0]) - 1 if self._csr is not None else super().__len__()
 
     def __iter__(self):
@@ -168,15 +177,38 @@ class _Front:
     cmask: Optional[torch.Tensor] = None       # chunk occupancy flags of `rows` (what the sweep stored into)
     arena: Optional[object] = None             # _lib.RowArena that lent `rows` (None: a tensor of its own)
     do_ratio: bool = False
+    fast: Optional[dict] = None                # handle of pipeline.issue: the whole device side is already in flight
+    stage1: Optional[object] = None            # refinement.DeviceStage1 whose first device pass rides along
 
 
-def projection_front(ds: DeviceScene, cfg, debug_out: bool = False, timers=None) -> _Front:
-    """First half of P:402-634 for one uploaded scene: RLE decode, fused sweep, point-filter threshold, row
-    statistics and the components of the merge graph.  Pure device work -- nothing here waits for the GPU, so
-    a caller can issue the front of the next scene on another stream while the host finishes this one
-    (`projection_back`)."""
+def fast_path_ok(ds: DeviceScene) -> bool:
+    """bff_scene_project handles every scene with masks and frames; BFF_NO_FAST=1 forces the step-by-step path."""
+    return (ds.n_rows > 0 and ds.n_points > 0 and ds.view_mask_offs.shape[0] > 1 and ds.n_mask_frames > 0
+            and ds.xyz.is_cuda and os.environ.get("BFF_NO_FAST") != "1")
+
+
+def projection_front(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, stage1=None, fast=None) -> _Front:
+    """Issue the device work of P:402-634 for one uploaded scene.  Nothing here waits for the GPU, so a caller can
+    issue the next scene on another stream while the host finishes this one (`projection_back`).
+
+    Fast form (default unless debug_out): ONE native call (bff_scene_project) enqueues everything -- RLE decode,
+    fused sweep, point filter, row statistics, components, the groups of P:203-226 formed on the device, OR of the
+    members, overlap resolution, size-filter counts and, when `stage1` (a refinement.DeviceStage1 of the same
+    scene) is given, the refinement's first device pass (R:186-217) -- and ends with an asynchronous copy of a
+    small header to the host.  Step-by-step form (debug_out, or fast=False): decode, sweep, threshold, statistics
+    and components are issued one by one and `projection_back` continues on the host."""
+    if fast is None:
+        fast = not debug_out
+    if fast and fast_path_ok(ds) and (stage1 is None or stage1.n_points == ds.n_points):
+        do_ratio = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
+        fr = _Front(ds, cfg, {}, False, do_ratio=do_ratio, stage1=stage1)
+        with sweep_span(timers, "project_views"), merge_span(timers, "merge_components"):
+            fr.fast = pipeline.issue(ds, cfg, DEPTH_THRESH, stage1, ds.n_frames if do_ratio else ds.n_mask_frames)
+        return fr
     with _lib.launch_stream():
-        return _projection_front(ds, cfg, debug_out, timers)
+        fr = _projection_front(ds, cfg, debug_out, timers)
+        fr.stage1 = stage1
+        return fr
 
 
 def _projection_front(ds, cfg, debug_out, timers) -> _Front:
@@ -231,22 +263,113 @@ def _projection_front(ds, cfg, debug_out, timers) -> _Front:
         order = _lib.argsort_i64(sig, _lib.SIGNATURE_BITS)
         if ds.n_label_ids > 1:                    # several label strings: cluster by label first (stable on top)
             order = order[_lib.argsort_i64(ds.label_id[order.long()].to(torch.int64), 32).long()].contiguous()
-    with span(timers, "merge_components"):
+    with merge_span(timers, "merge_components"):
         fr.comp = _lib.merge_components(rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist)
     fr.area = area
     return fr
 
 
-def projection_back(fr: _Front, timers=None, phases=None, stage1=None) -> Stage2Result:
-    """Second half: read the components back, group, merge, filter, select (P:203-247, 583-634).  Must run on
-    the stream the front was issued on.
+def projection_back(fr: _Front, timers=None, phases=None, stage1=None, want_groups: bool = True) -> Stage2Result:
+    """Host half: wait for the device, apply the size filters (P:601-606), select, assemble (P:608-634).  Must run
+    on the stream the front was issued on.
 
-    stage1 (optional, a refinement.DeviceStage1 of the same scene): when the refinement of this class follows
-    in the same process, its first device pass (stage-1 decode, areas, stage-1 x stage-2 and stage-1 x stage-1
-    intersections, R:186-217) is issued here and read back with this stage's last fetch, which saves the
-    refinement a synchronisation; `refine_class` picks it up from the result when given the same object."""
+    stage1 (optional, a refinement.DeviceStage1 of the same scene; normally given to projection_front already):
+    when the refinement of this class follows in the same process, its first device pass (stage-1 decode, areas,
+    stage-1 x stage-2 and stage-1 x stage-1 intersections, R:186-217) is read back with this stage's fetch, which
+    saves the refinement a synchronisation; `refine_class` picks it up from the result when given the same object.
+    want_groups=False: skip keeping the reference's mask_indeces_to_be_merged lists (diagnostic output)."""
+    if stage1 is None:
+        stage1 = fr.stage1
     with _lib.launch_stream():
+        if fr.fast is not None:
+            return _fast_back(fr, stage1, want_groups)
         return _projection_back(fr, timers, phases, stage1)
+
+
+class _WsRows:
+    """RowArena look-alike for the general path running on a bff_scene_project workspace: release() clears the
+    chunks the sweep stored, which is what the fast path would have done on the device."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def release(self, rows, cmask):
+        _lib.call("bff_clear_flagged_chunks", _lib._ptr(rows, torch.int64), rows.shape[0], rows.shape[1],
+                  _lib._ptr(cmask, torch.int64))
+        self.ws.rows_dirty = False
+
+
+def _fast_back(fr: _Front, stage1, want_groups) -> Stage2Result:
+    from .pipeline import (GROUP_CAP, HDR_AFTER, HDR_BEFORE, HDR_CONF, HDR_CROSS, HDR_FIRST, HDR_K, HDR_NUNIQUE,
+                           HDR_SIZES, HDR_THR)
+    ds, cfg, dbg = fr.ds, fr.cfg, fr.dbg
+    h = fr.fast
+    ws, both, s1_rows = h["ws"], h["both"], h["s1_rows"]
+    hdr = pipeline.collect(h)                                        # the one synchronisation of the scene
+    dev = ds.xyz.device
+    n, nw = ds.n_points, ds.nw
+    k_all, flags = int(hdr[HDR_K]), int(hdr[HDR_K + 1])
+    filtered = h["params"].filter_mode != 0
+    if filtered:
+        thr = float(hdr[HDR_THR:HDR_THR + 1].view(np.float32)[0])
+        if hdr[HDR_NUNIQUE] == 0 or np.isnan(thr):
+            ws.rows_dirty = True
+            raise IndexError("index out of range: unique()[floor(t * n)] (P:516 / P:574)")
+        dbg["thr"] = thr
+    if flags:
+        # more groups than the device forms by itself (or min_aggragated_masks <= 0 with empty components): the
+        # group tables are incomplete -- continue from the components on the host, exactly as the step-by-step path
+        mw = max(_lib.load().bff_chunk_mask_words(nw), 1)
+        hd = ws.t["hdr"]
+        slow = _Front(ds, cfg, dbg, False, rows=ws.view("rows", ds.n_rows, nw), masked=ws.view("masked", n),
+                      viewed=ws.view("viewed", n) if fr.do_ratio else None, keep=ws.view("keep", nw),
+                      thr_dev=hd[HDR_THR:HDR_THR + 1].view(torch.float32) if filtered else None,
+                      lat_info=hd[HDR_NUNIQUE:HDR_NUNIQUE + 1] if filtered else None,
+                      area=ws.view("area", ds.n_rows), comp=ws.view("comp", ds.n_rows),
+                      cmask=ws.view("chunk_mask", ds.n_rows, mw), arena=_WsRows(ws), do_ratio=fr.do_ratio)
+        dbg["path"] = "general (device tables incomplete: %d groups, flags %d)" % (k_all, flags)
+        return _projection_back(slow, None, None, stage1 if (stage1 is not None and stage1.n_points == n) else None)
+    dbg["path"] = "fast"
+    k = k_all
+    if k == 0:                                                                      # P:230-236, 496-509
+        dbg["groups"] = []
+        return _empty(ds, dbg)
+    sizes = hdr[HDR_SIZES:HDR_SIZES + k]
+    first = hdr[HDR_FIRST:HDR_FIRST + k]
+    before, after = hdr[HDR_BEFORE:HDR_BEFORE + k], hdr[HDR_AFTER:HDR_AFTER + k]
+    conf_np = hdr[HDR_CONF:HDR_CONF + GROUP_CAP].view(np.float16 if ds.conf.dtype == torch.float16 else np.float32)[:k]
+    # a17: size filters with the reference's dtype promotion (P:601-606): `after > 5` on integers; `after > 0.4 *
+    # before` is an int64 tensor against python-float * int64 tensor = float32 arithmetic on both sides
+    keep_rows = (after > cfg.remove_small_masks) & \
+        (after.astype(np.float32) > np.float32(cfg.remove_filtered_masks) * before.astype(np.float32))
+    sel = np.flatnonzero(keep_rows).astype(np.int32)
+    dbg.update(before=torch.from_numpy(before.astype(np.int64)), after=torch.from_numpy(after.astype(np.int64)),
+               keep=torch.from_numpy(keep_rows))
+    agg_u = both[:GROUP_CAP]
+    if sel.size:
+        out_rows = _lib.gather_rows(agg_u, _lib.upload(sel, torch.int32, dev))
+        conf_host = torch.from_numpy(conf_np[sel].copy())
+        out_conf = _lib.upload(conf_np[sel], ds.conf.dtype, dev)
+    else:
+        out_rows = agg_u[:0]
+        conf_host = torch.from_numpy(conf_np[:0].copy())
+        out_conf = torch.zeros(0, dtype=ds.conf.dtype, device=dev)
+    labels = ds.labels
+    out_labels = [labels[first[g]] for g in sel]
+    pre = None
+    if s1_rows and stage1 is not None:
+        cross = hdr[HDR_CROSS:HDR_CROSS + s1_rows * (GROUP_CAP + s1_rows)].reshape(s1_rows, GROUP_CAP + s1_rows)
+        inter11 = np.ascontiguousarray(cross[:, GROUP_CAP:])
+        pre = dict(stage1=stage1, s1=both[GROUP_CAP:], area1=np.ascontiguousarray(np.diagonal(inter11)),
+                   area2=after[sel], inter=np.ascontiguousarray(cross[:, sel]), inter11=inter11)
+    if want_groups:
+        # mask_indeces_to_be_merged (P:203-247) stays on the device until someone looks at it
+        total = int(sizes.sum())
+        groups = _LazyGroups(None, None, fetch=(ws.view("goffs", k + 1).clone(), ws.view("gmembers", total).clone()))
+    else:
+        groups = _LazyGroups(np.zeros(1, np.int32), np.zeros(0, np.int32))
+    dbg["groups"] = groups
+    return Stage2Result(ds.scene_id, n, out_rows, out_conf, out_labels, groups, dbg, conf_host, pre)
 
 
 def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, phases=None, stage1=None) -> Stage2Result:
@@ -255,7 +378,7 @@ def run_projection(ds: DeviceScene, cfg, debug_out: bool = False, timers=None, p
     if phases is not None:
         import time
         t0 = time.perf_counter()
-    fr = projection_front(ds, cfg, debug_out, timers)
+    fr = projection_front(ds, cfg, debug_out, timers, stage1=stage1, fast=False if phases is not None else None)
     if phases is not None:
         torch.cuda.synchronize()
         phases["front (decode, sweep, threshold, stats, components)"] = \

@@ -59,17 +59,24 @@ def _hash32(x: torch.Tensor) -> torch.Tensor:
 
 
 def _cuboids(rng: np.random.Generator, n_obj: int = 10):
+    """n_obj axis-aligned cuboids standing on the floor: 10 on a 5 x 2 grid (the default scenes), more on a
+    denser grid with proportionally smaller footprints."""
     lo, hi = [], []
-    gx = np.linspace(0.9, 5.1, 5)
-    gy = np.array([1.0, 3.0])
+    if n_obj <= 10:
+        gx, gy, scale = np.linspace(0.9, 5.1, 5), np.array([1.0, 3.0]), 1.0
+    else:
+        nx = int(math.ceil(math.sqrt(n_obj * 1.5)))
+        ny = int(math.ceil(n_obj / nx))
+        gx, gy = np.linspace(0.6, 5.4, nx), np.linspace(0.5, 3.5, ny)
+        scale = min(4.8 / nx, 3.0 / ny) / 1.3
     k = 0
     for y in gy:
         for x in gx:
             if k >= n_obj:
                 break
-            sx, sy = rng.uniform(0.4, 0.9, 2)
+            sx, sy = rng.uniform(0.4, 0.9, 2) * scale
             h = rng.uniform(0.4, 1.2)
-            cx, cy = x + rng.uniform(-0.1, 0.1), y + rng.uniform(-0.3, 0.3)
+            cx, cy = x + rng.uniform(-0.1, 0.1) * scale, y + rng.uniform(-0.3, 0.3) * scale
             lo.append([cx - sx / 2, cy - sy / 2, 0.0])
             hi.append([cx + sx / 2, cy + sy / 2, h])
             k += 1
@@ -148,15 +155,21 @@ def _rle_from_dense(dense: torch.Tensor):
 def make_scene(shape="c1", seed: int = 0, device="cpu", query: str = "table", n_labels: int = 1,
                n_points: int = None, n_views: int = None, height: int = None, width: int = None,
                n_masks: int = None, downsample_ratio: int = 10, n_stage1: int = 100,
-               shuffle_points: bool = True, conf_dtype=torch.float16) -> SceneInputs:
+               shuffle_points: bool = True, conf_dtype=torch.float16, cut_masks: bool = True,
+               n_objects: int = 10, distinct_masks: bool = False, dilate: bool = True) -> SceneInputs:
     """Build one synthetic scene.  `shape` names a BASELINE config (see SHAPES); explicit
-    keyword sizes override it.  `n_labels` > 1 mixes several label strings among the masks."""
+    keyword sizes override it.  `n_labels` > 1 mixes several label strings among the masks.
+    cut_masks=False: every 2-D mask is the whole (dilated) silhouette of its object instead of a random half of
+    it -- the views of one object then merge into one instance and most instances survive the filters (a scene
+    with many stage-2 instances for the benchmark; the default keeps the golden fixtures' scenes).
+    n_objects: number of cuboids; distinct_masks=True: a view's masks show different objects as far as there are
+    visible ones (then repeats), instead of independent draws; dilate=False: exact silhouettes (no 1-3 px bleed)."""
     n0, v0, h0, w0, m0 = SHAPES[shape] if isinstance(shape, str) else shape
     n, v_all = n_points or n0, n_views or v0
     h, w, m_per = height or h0, width or w0, n_masks or m0
     rng = np.random.default_rng(seed)
     device = torch.device(device)
-    lo, hi = _cuboids(rng)
+    lo, hi = _cuboids(rng, n_objects)
     n_obj = lo.shape[0]
 
     # ---- cloud: half on the room faces, half on the cuboids (area weighted)
@@ -205,7 +218,11 @@ def make_scene(shape="c1", seed: int = 0, device="cpu", query: str = "table", n_
         visible = [k for k in range(n_obj) if bool((oid == k).any())]
         if not visible:
             continue                               # segmentation_2d.py:271-274: frame skipped
-        chosen = rng.choice(visible, size=m_per, replace=True)
+        if distinct_masks:
+            order = rng.permutation(visible)
+            chosen = np.resize(order, m_per)
+        else:
+            chosen = rng.choice(visible, size=m_per, replace=True)
         vv, uu = torch.meshgrid(torch.arange(h, device=device, dtype=torch.float32),
                                 torch.arange(w, device=device, dtype=torch.float32), indexing="ij")
         dense = torch.zeros((m_per, h, w), dtype=torch.bool, device=device)
@@ -214,14 +231,17 @@ def make_scene(shape="c1", seed: int = 0, device="cpu", query: str = "table", n_
             ys, xs = torch.nonzero(base, as_tuple=True)
             x0, x1, y0, y1 = xs.min().item(), xs.max().item(), ys.min().item(), ys.max().item()
             # keep a random half-plane through the box that retains 50-100 % of its extent
-            if rng.random() < 0.5:
+            if not cut_masks:
+                part = base
+                rng.random(); rng.uniform(0.5, 1.0); rng.random()       # same random stream as the cut variant
+            elif rng.random() < 0.5:
                 cut = x0 + (x1 - x0 + 1) * rng.uniform(0.5, 1.0)
                 part = base & ((uu <= cut) if rng.random() < 0.5 else (uu >= x0 + x1 - cut))
             else:
                 cut = y0 + (y1 - y0 + 1) * rng.uniform(0.5, 1.0)
                 part = base & ((vv <= cut) if rng.random() < 0.5 else (vv >= y0 + y1 - cut))
             r = int(rng.integers(1, 4))
-            dense[j] = torch.nn.functional.max_pool2d(part[None, None].float(), 2 * r + 1, 1, r)[0, 0] > 0
+            dense[j] = (torch.nn.functional.max_pool2d(part[None, None].float(), 2 * r + 1, 1, r)[0, 0] > 0) if dilate else part
         conf = torch.from_numpy(rng.uniform(0.2, 0.5, m_per)).to(conf_dtype)
         mask_2d.append({
             "frame_id": f"{fid}.jpg",

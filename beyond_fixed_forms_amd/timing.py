@@ -34,6 +34,19 @@ class KernelTimers:
         yield
         self._events[name].append((ctypes.c_void_p(a), ctypes.c_void_p(b)))
 
+    @contextlib.contextmanager
+    def merge_span(self, name):
+        """Span of the components' tile pass (bff_profile_next_merge): the kernel's own duration."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        a, b = lib.bff_event_create(), lib.bff_event_create()
+        if not a or not b:
+            raise RuntimeError("bff_event_create failed")
+        lib.bff_profile_next_merge(a, b)
+        yield
+        self._events[name].append((ctypes.c_void_p(a), ctypes.c_void_p(b)))
+
     def summary(self):
         """{name: (launches, total_ms, mean_ms)} -- call after a device synchronize."""
         import ctypes
@@ -78,4 +91,13 @@ def sweep_span(timers, name):
         yield
     else:
         with timers.sweep_span(name):
+            yield
+
+
+@contextlib.contextmanager
+def merge_span(timers, name):
+    if timers is None:
+        yield
+    else:
+        with timers.merge_span(name):
             yield

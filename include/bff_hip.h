@@ -362,6 +362,110 @@ int bff_cosine_gemm_f16(const void *a, int32_t na, const void *b, int32_t nb, in
 int bff_cosine_rows(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim, int32_t dtype,
                     float *cos, void *stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Groups formed on the device (P:203-226 without the host round trip) and the whole scene in one call.
+ */
+#define BFF_GROUP_CAP 64          /* groups the device forms by itself (= rows of the fused overlap pass) */
+#define BFF_SIGNATURE_BITS 30     /* bff_row_stats signatures are 30-bit keys */
+
+/* Device twin of bff_host_component_csr for at most `cap` <= BFF_GROUP_CAP kept groups.  comp[i] = smallest row index
+ * of i's component (bff_merge_components).  Outputs (device): info[4] = {K kept groups (may exceed cap), flags (bit 0:
+ * K > cap, bit 1: min_members <= 0 and empty components exist -- both: use the host path), largest group, number of
+ * 32-member slices}; sizes[cap], first[cap] (= smallest member = where the group's label comes from), offs[cap+1],
+ * members[n_rows] (ascending inside a group), slices[3 * bff_group_slice_cap(n_rows, cap)] (work items of
+ * bff_or_reduce_grouped); count: scratch int32 [n_rows]. */
+int32_t bff_group_slice_cap(int32_t n_rows, int32_t cap);
+int bff_group_components(const int32_t *comp, const int32_t *area, int32_t n_rows, float iou_thres,
+                         int32_t min_members, int32_t cap, int32_t *count, int32_t *info, int32_t *sizes,
+                         int32_t *first, int32_t *offs, int32_t *members, int32_t *slices, void *stream);
+/* bff_or_reduce_groups for those groups: out [cap][nw] (zeroed here; rows >= K stay zero), conf_mean [cap] in the
+ * confidence dtype. */
+int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n_rows, const int32_t *info, int32_t cap,
+                          const int32_t *offs, const int32_t *members, const int32_t *slices, uint64_t *out,
+                          const void *conf, int32_t conf_dtype, void *conf_mean, void *stream);
+/* bff_resolve_overlaps with the row count on the device (*k_dev <= k_cap, else nothing is touched); inter is
+ * [k_cap][k_cap]. */
+int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *inter, const int32_t *size,
+                             const uint64_t *keep, int32_t *before, int32_t *after, const int32_t *k_dev, void *stream);
+/* bff_clear_flagged_chunks unless *veto != 0 (device flag). */
+int bff_clear_flagged_chunks_unless(uint64_t *rows, int32_t n_rows, int64_t nw, const uint64_t *chunk_mask,
+                                    const int32_t *veto, void *stream);
+
+/* Device-resident inputs of one scene (what scene.prepare_scene uploads; all pointers are device pointers). */
+typedef struct bff_scene {
+    int64_t n_points, n_pad, nw;
+    const double *xyz;              /* [3][n_pad] */
+    const double *tile_bounds;      /* bff_point_tile_bounds table or NULL */
+    const double *inv_pose;         /* [n_frames][16] */
+    double cam_intr[9];
+    const float *depth;
+    const int32_t *depth_index, *frame_mask, *frame_rowbase, *frame_nmask, *frame_flags;   /* [n_frames] */
+    const int32_t *run_start, *run_end, *mask_run_offs, *view_mask_offs;                     /* 2-D RLE run tables */
+    const void *conf;               /* [n_rows] float16 / float32 */
+    const int32_t *label_id;        /* [n_rows] */
+    const int32_t *unsort;          /* [n_points] or NULL */
+    const int32_t *s1_run_start, *s1_run_end, *s1_row_run_offs;     /* stage-1 run tables or NULL */
+    int32_t height, width, n_frames, n_mviews, word_bits, n_rows, conf_f16, n_label_ids, s1_rows, pad_;
+} bff_scene;
+
+typedef struct bff_scene_params {
+    double depth_thresh;            /* 0.08 at P:438,565 */
+    double filter_fraction;         /* occurance_threshold / detected_ratio_threshold */
+    float iou_thres;
+    int32_t min_members;            /* cfg.min_aggragated_masks */
+    int32_t filter_mode;            /* 0 none, 1 occurrence (P:512-522), 2 detection ratio (P:524-578) */
+    int32_t pad_;
+} bff_scene_params;
+
+/* Scratch of bff_scene_project, allocated by the caller for the scene's sizes (beyond_fixed_forms_amd/pipeline.py).
+ * `rows` must be all zero on entry; it is all zero again when the call's work has run on the fast path. */
+typedef struct bff_scene_workspace {
+    void *maskbits; uint32_t *segmap;
+    uint64_t *rows, *chunk_mask, *keep, *tile_mask, *agg, *both;
+    int32_t *masked, *viewed, *sel_scratch, *area, *mean_word, *order, *parent, *comp, *count;
+    int32_t *gmembers, *goffs, *slices, *inter;
+    float *vals, *vals_sorted;
+    uint32_t *hist, *merge_scratch;
+    int64_t *sig, *sig_keys, *sig_sorted;
+    void *sort_temp; size_t sort_temp_bytes;
+    int32_t *hdr;                   /* device, bff_scene_header_words(s1_rows) int32 */
+    int32_t *hdr_host;              /* pinned host mirror of the same size */
+} bff_scene_workspace;
+
+/* Header layout (int32 words). */
+#define BFF_HDR_K 0                 /* info[4] of bff_group_components: K, flags, largest group, slices */
+#define BFF_HDR_NUNIQUE 4           /* distinct filter values (0: the reference would raise IndexError) */
+#define BFF_HDR_THR 5               /* float32 threshold */
+#define BFF_HDR_SIZES 16            /* [64] members per group */
+#define BFF_HDR_FIRST 80            /* [64] smallest member of the group */
+#define BFF_HDR_BEFORE 144          /* [64] popcount before overlap resolution (P:592) */
+#define BFF_HDR_AFTER 208           /* [64] popcount after overlaps + point filter (P:596) */
+#define BFF_HDR_CONF 272            /* [64] confidence means, in the confidence dtype, packed */
+#define BFF_HDR_CROSS 336           /* [s1_rows][64 + s1_rows] stage-1 x (stage-2 groups | stage-1) intersections */
+int32_t bff_scene_header_words(int32_t s1_rows);
+int32_t bff_scene_struct_bytes(int32_t which);     /* 0 bff_scene, 1 bff_scene_params, 2 bff_scene_workspace */
+
+/* The whole device side of one scene on `stream`, ending with an asynchronous copy of the header into
+ * ws->hdr_host: nothing in it waits for the host.  After the stream has reached that copy the host reads K,
+ * flags, sizes, first members, before/after counts, confidence means and the refinement's intersections from
+ * the header; ws->both holds the K aggregated, overlap-resolved, filtered rows in the caller's point order followed
+ * by the decoded stage-1 rows.  flags != 0: the group tables are incomplete -- continue from ws->comp / ws->area on
+ * the host (projection._projection_back), ws->rows is then still intact. */
+int bff_scene_project(const bff_scene *scene, const bff_scene_params *params, const bff_scene_workspace *ws,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ingestion: cloud layout on the device.  pts: float64 [n][stride] exactly as <scene>.npy
+ * holds it (P:387: stride 6, xyz first).  Writes the structure-of-arrays cloud the sweep reads (soa [3][n_pad], pad
+ * zeroed) and, with sort != 0, orders the points along a 30-bit Morton curve over their bounding box first (same
+ * codes and a stable sort as scene.morton_order on the host -> the same permutation): unsort[o] = position of
+ * original point o, perm = its inverse.  codes: uint32 [2 n], box: float64 [6], temp: sort scratch (temp == NULL:
+ * size query into *temp_bytes). */
+int bff_cloud_layout(const double *pts, int64_t n, int64_t stride, int64_t n_pad, int32_t sort, double *soa,
+                     int32_t *unsort, int32_t *perm, uint32_t *codes, double *box, void *temp, size_t *temp_bytes,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

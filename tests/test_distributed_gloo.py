@@ -38,7 +38,33 @@ def _worker(rank, world, port, q):
     assert (g2 is None) == (gathered is None)
     if g2 is not None:
         assert [g.tolist() for g in g2] == [g.tolist() for g in gathered]
-    q.put((rank, mine, thr, None if gathered is None else [g.tolist() for g in gathered]))
+    # the result transport of run_class: descriptor rows + bit rows + confidences in ONE padded gather
+    ids = [f"scene{i:04d}_00" for i in range(5)]
+    gen = torch.Generator().manual_seed(rank)
+    local = {}
+    for i in mine:
+        r = (i * 3 + 1) % 4                                   # 1, 0 (-> empty tensor form), 3, 2, ... rows
+        if i == 3:
+            local[ids[i]] = (None, [], [])                    # the reference's list-valued empty form
+        else:
+            local[ids[i]] = (torch.randint(-2 ** 62, 2 ** 62, (r, 5 + i), generator=gen),
+                             torch.rand(r, generator=gen).to(torch.float16 if i % 2 else torch.float32), ["q"] * r)
+    s_max = 3
+    ex2 = bd.ClassExchange()
+    ex2([[0.1]], bounds=(sum(0 if v[0] is None else v[0].shape[0] for v in local.values()),
+                         max([v[0].shape[1] for v in local.values() if v[0] is not None] + [1])))
+    mat = bd.pack_class_results(local, {sid: k for k, sid in enumerate(ids)}, s_max, "cpu")
+    g3 = bd.gather_final_rows(mat, bounds=(s_max + ex2.bounds[0], max(ex2.bounds[1], 4) + 1))
+    merged = None
+    if g3 is not None:
+        merged = {}
+        for g in g3:
+            merged.update(bd.unpack_class_results(g.rows(), ids, s_max, "q"))
+        merged = {k: (None if v[0] is None else v[0].tolist(), v[1] if isinstance(v[1], list) else (str(v[1].dtype), v[1].tolist()), v[2])
+                  for k, v in merged.items()}
+    mine_plain = {k: (None if v[0] is None else v[0].tolist(), v[1] if isinstance(v[1], list) else (str(v[1].dtype), v[1].tolist()), v[2])
+                  for k, v in local.items()}
+    q.put((rank, mine, thr, None if gathered is None else [g.tolist() for g in gathered], mine_plain, merged))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,7 +78,8 @@ def test_two_ranks_gloo():
     out = sorted(q.get(timeout=120) for _ in range(world))
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    (r0, mine0, thr0, g0), (r1, mine1, thr1, g1) = out
+    (r0, mine0, thr0, g0, loc0, merged0), (r1, mine1, thr1, g1, loc1, merged1) = out
+    assert merged1 is None and merged0 == {**loc0, **loc1} and len(merged0) == 5      # rank 0 holds every scene's result
     assert mine0 == [0, 2, 4] and mine1 == [1, 3]
     from beyond_fixed_forms_amd.refinement import sim_threshold
     single = sim_threshold([[0.31, 0.12], [], [0.12, 0.77, 0.5], [0.05], [0.31]], 0.2)

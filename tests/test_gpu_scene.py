@@ -294,7 +294,7 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.load()
 
 
-def _run_class_worker(rank, world, port, q):
+def _run_class_worker(rank, world, port, q, over=None):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -306,7 +306,12 @@ def _run_class_worker(rank, world, port, q):
     scenes = [make_scene("tiny", seed=50 + i) for i in range(5)]
     for i, sc in enumerate(scenes):
         sc.scene_id = f"scene{50 + i:04d}_00"
-    cfg = Config.with_defaults(width_2d=scenes[0].width, height_2d=scenes[0].height)
+    cfg = Config.with_defaults(width_2d=scenes[0].width, height_2d=scenes[0].height, **(over or {}))
+    if over:                      # occurrence mode loads no viewed-only frames from disk: drop them here too
+        for sc in scenes:
+            keep = {f["frame_id"][:-4] for f in sc.mask_2d}
+            sc.poses = {k: v for k, v in sc.poses.items() if k in keep}
+            sc.depths = {k: v for k, v in sc.depths.items() if k in keep}
     bank, index = make_text_bank(64, seed=7)
     out = bd.run_class(scenes, cfg, "table", TextSimilarity(bank_encoder(bank.float(), index), DEV), DEV,
                        weights=[s.points.shape[0] * len(s.mask_2d) for s in scenes])
@@ -316,9 +321,11 @@ def _run_class_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_run_class_two_ranks_equals_single_process(api):
-    """distributed.run_class with 2 ranks (sharded scenes, pooled similarity sets, gathered bit rows) gives,
-    on rank 0, exactly the results of the single-process class loop -- and of the oracle."""
+@pytest.mark.parametrize("over", [None, dict(if_occurance_threshold=True)], ids=["ratio", "occurrence"])
+def test_run_class_two_ranks_equals_single_process(api, over):
+    """distributed.run_class with 2 ranks (sharded scenes, ONE all-gather of similarity sets + row bounds, ONE
+    gather of padded result matrices) gives, on rank 0, exactly the results of the single-process class loop --
+    and of the oracle.  Occurrence mode: scenes as io.load_scene delivers them, without the viewed-only frames."""
     import socket
     import torch.multiprocessing as mp
     projection, refinement = api
@@ -326,7 +333,7 @@ def test_run_class_two_ranks_equals_single_process(api):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_run_class_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run_class_worker, args=(r, 2, port, q, over)) for r in range(2)]
     [p.start() for p in procs]
     got = q.get(timeout=300)
     [p.join(timeout=120) for p in procs]
@@ -334,7 +341,7 @@ def test_run_class_two_ranks_equals_single_process(api):
     scenes = [make_scene("tiny", seed=50 + i) for i in range(5)]
     for i, sc in enumerate(scenes):
         sc.scene_id = f"scene{50 + i:04d}_00"
-    cfg = cfg_for(scenes[0])
+    cfg = cfg_for(scenes[0], **(over or {}))
     bank, index = make_text_bank(64, seed=7)
     enc = bank_encoder(bank.float(), index)
     trip = []
@@ -417,3 +424,106 @@ def test_similarity_set_near_ties(api, enc_dtype):
         same(fin[sid].to_dict(), fexp[sid])
     dropped = sum(5 + 1 - fexp[sid]["ins"].shape[0] for sid, _, _ in scenes_p)     # 5 matched + 1 other per scene
     assert dropped > 0                                                    # the threshold did bite
+
+
+@pytest.mark.parametrize("case", ["more_than_64_groups", "min_members_0", "many_stage2"])
+def test_fast_path_and_its_fallbacks(api, case):
+    """bff_scene_project (one native call per scene, groups formed on the device) against the oracle and against the
+    step-by-step path: (a) a scene whose merge graph has more than 64 kept groups -- the device tables are
+    incomplete, the host continues from the components (general path); (b) min_aggragated_masks = 0, where the
+    reference's empty components survive the filter (general path too); (c) a scene with many surviving stage-2
+    instances on the fast path.  Stage-2 and final results are bit-identical in all cases."""
+    projection, refinement = api
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    from beyond_fixed_forms_amd.synthetic import make_scene, make_text_bank
+    over = {}
+    if case == "more_than_64_groups":
+        scene = make_scene("tiny", seed=30, n_labels=12, n_masks=64, n_views=6, cut_masks=False)
+    elif case == "min_members_0":
+        scene = make_scene("tiny", seed=31)
+        over = dict(min_aggragated_masks=0)
+    else:
+        scene = make_scene("c1", seed=32, n_views=40, n_masks=30, cut_masks=False, n_objects=30, distinct_masks=True,
+                           dilate=False)
+    cfg = cfg_for(scene, **over)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp, dbg = pref.project_scene_ref(scene, cfg, return_debug=True)
+    st1 = refinement.prepare_stage1(scene.stage1, DEV)
+    ds = prepare_scene(scene, cfg, device=DEV)
+    res = projection.run_projection(ds, cfg, stage1=st1)                       # fast front
+    slow = projection.run_projection(ds, cfg, debug_out=True)                  # step by step
+    if case == "many_stage2":
+        assert res.debug["path"] == "fast" and exp["ins"].shape[0] >= 5
+    else:
+        assert res.debug["path"].startswith("general")
+        if case == "more_than_64_groups":
+            assert len(dbg["groups"]) > 64
+    assert list(res.groups) == list(slow.groups) == dbg["groups"]
+    same(res.to_dict(), exp)
+    same(slow.to_dict(), exp)
+    assert torch.equal(res.rows, slow.rows) and torch.equal(res.conf, slow.conf)
+    assert abs(res.debug["thr"] - slow.debug["thr"]) == 0
+    bank, index = make_text_bank(64, seed=3)
+    enc = bank_encoder(bank, index)                                            # float16 embeddings, as CLIP on a GPU
+    sim = refinement.TextSimilarity(enc, DEV)
+    if len(exp["conf"]) == 0:
+        return
+    fexp = rref.refine_class_ref([(scene.scene_id, scene.stage1, exp)], cfg, "table", enc)
+    assert res.prefetch is not None
+    fin = refinement.refine_class([(scene.scene_id, st1, res)], cfg, "table", sim, DEV)
+    same(fin[scene.scene_id].to_dict(), fexp[scene.scene_id])
+    # the workspace is reused: a second scene through the same stream, then the first one again
+    other = make_scene("tiny", seed=33)
+    ocfg = cfg_for(other)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        oexp = pref.project_scene_ref(other, ocfg)
+    same(projection.run_projection(prepare_scene(other, ocfg, device=DEV), ocfg).to_dict(), oexp)
+    again = projection.run_projection(ds, cfg)
+    same(again.to_dict(), exp)
+    assert list(again.groups) == dbg["groups"]
+
+
+def test_overlapped_ingestion_equals_prepare_scene(api):
+    """ingest.prepare_scene_fast (native run tables, batched pose inverses, packed pinned uploads, cloud sorted and
+    laid out on the device) builds the same DeviceScene as scene.prepare_scene -- same sorted cloud, same inverse
+    permutation, same inverse poses bit for bit, same depth -- and the Ingestor's loader threads (own streams, events)
+    feed the device path with identical results, for float32 depth and for raw 16-bit depth resized on the device."""
+    projection, refinement = api
+    from beyond_fixed_forms_amd import ingest
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    from beyond_fixed_forms_amd.synthetic import make_scene
+    scenes = [make_scene("tiny", seed=60 + i, n_masks=(5, 40, 9)[i]) for i in range(3)]
+    cfg = cfg_for(scenes[0])
+    for sc in scenes:
+        a = prepare_scene(sc, cfg, device=DEV)
+        b = ingest.prepare_scene_fast(sc, cfg, device=DEV)
+        torch.cuda.synchronize()
+        for k in ("xyz", "unsort", "inv_pose", "depth", "depth_index", "frame_mask", "frame_rowbase", "frame_nmask",
+                  "frame_flags", "view_mask_offs", "conf", "label_id", "tile_bounds", "mask_run_offs", "run_start", "run_end"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), k
+        assert (a.n_frames, a.n_mask_frames, a.n_viewed, a.word_bits, a.n_rows, a.labels) == \
+               (b.n_frames, b.n_mask_frames, b.n_viewed, b.word_bits, b.n_rows, b.labels)
+    # raw 16-bit frames at half resolution, scaled + resized on the device: same as the step-by-step upload of them
+    import copy
+    raw = copy.copy(scenes[0])
+    raw.depths_raw = {f: np.ascontiguousarray(np.round(d[::2, ::2].astype(np.float64) * 1000).astype(np.uint16))
+                      for f, d in raw.depths.items()}
+    a, b = prepare_scene(raw, cfg, device=DEV), ingest.prepare_scene_fast(raw, cfg, device=DEV)
+    assert torch.equal(a.depth, b.depth) and a.depth.shape[1] == cfg.height_2d * cfg.width_2d
+    # loader threads: results through the pipeline == results of the plain path == oracle
+    ing = ingest.Ingestor(cfg, DEV, n_loaders=2, native_threads=2)
+    futs = [ing.submit(sc) for sc in scenes * 2]
+    st = torch.cuda.Stream(device=DEV)
+    for i, f in enumerate(futs):
+        ds, st1, ev = f.result()
+        st.wait_event(ev)
+        with torch.cuda.stream(st):
+            res = projection.run_projection(ds, cfg, stage1=st1)
+        sc = scenes[i % 3]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            exp = pref.project_scene_ref(sc, cfg)
+        same(res.to_dict(), exp)
+    ing.close()

@@ -220,3 +220,51 @@ def test_bilinear_resize_hand_derived_fixture():
     assert big[2][1000] == np.float32(f - np.float32(np.floor(f)))
     # identity
     assert np.array_equal(io.resize_bilinear_f32(src, 3, 2), src)
+
+
+def test_native_run_tables_match_the_numpy_builder():
+    """libbff_host.so (ingestion): RLE dicts -> run tables with the decode semantics of rle_decode_batch (RLE:45-57)
+    == scene.runs_from_rles up to the empty runs the native builder keeps in place (start == end: they decode to
+    nothing); inputs it declines (overlapping / unsorted runs) return None, malformed ones raise like the NumPy path."""
+    from beyond_fixed_forms_amd import ingest
+    from beyond_fixed_forms_amd.scene import runs_from_rles
+    from beyond_fixed_forms_amd.synthetic import make_scene
+
+    class HostStaging(ingest.Staging):           # pageable stand-in: pinned memory needs a GPU runtime
+        def get(self, name, nbytes):
+            t = self.buf.get(name)
+            if t is None or t.numel() < nbytes:
+                t = self.buf[name] = torch.empty(max(int(nbytes), 64), dtype=torch.uint8)
+            return t
+
+    st = HostStaging()
+    sc = make_scene("tiny", seed=6, n_masks=7)
+    rles = [r for fr in sc.mask_2d for r in fr["segmented_frame_masks"]]
+    hw = sc.height * sc.width
+    for threads in (1, 3):
+        got = ingest.pack_rles(rles, hw, st, "m", threads)
+        exp = runs_from_rles(rles)
+        assert all(np.array_equal(g.numpy(), e) for g, e in zip(got, exp))
+    # int32 counts, an empty mask, a full mask, a run clipped by the end, a run entirely past the end, zero-length runs
+    odd = [dict(length=50, counts=np.array([], dtype=np.int64)), dict(length=50, counts=np.array([1, 50])),
+           dict(length=50, counts=np.array([3, 4, 20, 1, 45, 10], dtype=np.int32)), dict(length=50, counts=np.array([60, 5])),
+           dict(length=50, counts=np.array([5, 0, 5, 3, 8, 0, 9, 2]))]
+    rs, re, offs = (t.numpy() for t in ingest.pack_rles(odd, 50, st, "o", 2))
+    dense = lambda s, e, o: [sorted(set(p for k in range(o[g], o[g + 1]) for p in range(s[k], e[k]))) for g in range(len(o) - 1)]
+    assert dense(rs, re, offs) == dense(*runs_from_rles(odd))
+    assert all(np.all(np.diff(re[offs[g]:offs[g + 1]]) >= 0) for g in range(len(odd)))       # ends stay monotone
+    assert ingest.pack_rles([dict(length=50, counts=np.array([10, 10, 15, 10]))], 50, st, "x") is None     # overlap: slow path
+    assert ingest.pack_rles([dict(length=50, counts=np.array([20, 2, 5, 2]))], 50, st, "x") is None        # unsorted
+    assert ingest.pack_rles([dict(length=50, counts=np.array([1.0, 2.0]))], 50, st, "x") is None           # not integers
+    with pytest.raises(ValueError):
+        ingest.pack_rles([dict(length=50, counts=np.array([0, 3]))], 50, st, "x")                          # start < 1
+    with pytest.raises(ValueError):
+        ingest.pack_rles([dict(length=50, counts=np.array([1, 3, 7]))], 50, st, "x")                       # odd
+    with pytest.raises(ValueError):
+        ingest.pack_rles([dict(length=49, counts=np.array([1, 3]))], 50, st, "x")                          # length != H*W
+    # frames
+    frames = [np.full((5, 7), k, np.uint16) for k in range(9)]
+    dst = torch.empty(9 * 70, dtype=torch.uint8)
+    assert ingest.host_lib().bff_host_pack_frames(frames, dst.data_ptr(), 70, 3) == 9
+    assert np.array_equal(dst.numpy().view(np.uint16).reshape(9, 5, 7), np.stack(frames))
+    assert ingest.host_lib().bff_host_pack_frames(frames + [np.zeros((5, 8), np.uint16)], dst.data_ptr(), 70, 2) == -1
