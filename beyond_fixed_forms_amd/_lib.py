@@ -50,11 +50,15 @@ SIGNATURES = {
     "bff_select_unique_rank": [_P, _L, _D, _P, _P, _P, _P],
     "bff_cosine_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
     "bff_cosine_rows": [_P, _I, _P, _I, _I, _I, _P, _P],
+    "bff_normalized_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
+    "bff_description_means": [_P, _P, _I, _I, _I, _P, _P],
     "bff_group_components": [_P, _P, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "bff_or_reduce_grouped": [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
     "bff_resolve_overlaps_dev": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P],
     "bff_clear_flagged_chunks_unless": [_P, _I, _L, _P, _P, _P],
     "bff_scene_project": [_P, _P, _P, _P],
+    "bff_scatter_bits": [_P, _I, _L, _P, _L, _L, _P, _P, _P],
+    "bff_cross_popcount_dev": [_P, _I, _P, _I, _L, _P, _P, _I, _I, _P],
     "bff_cloud_layout": [_P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "bff_sort_f32": [_P, _P, _L, _P, _P, _P],
     "bff_argsort_i64": [_P, _P, _P, _I, _I, _P, _P, _P],
@@ -624,4 +628,24 @@ def cosine_rows(a, b):
     out = torch.empty((a.shape[0], b.shape[0]), dtype=f32, device=a.device)
     call("bff_cosine_rows", _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1],
          1 if a.dtype == torch.float16 else 0, _ptr(out))
+    return out
+
+
+def normalized_gemm_f16(a, b):
+    """F.normalize(a) @ b.T for float16 rows (SEG:388-393: b = the already normalised text means): float32 [na][nb]."""
+    if a.dtype != torch.float16 or b.dtype != torch.float16:
+        raise TypeError("normalized_gemm_f16 takes float16 operands")
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=f32, device=a.device)
+    call("bff_normalized_gemm_f16", _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], _ptr(out))
+    return out
+
+
+def description_means(desc, offs):
+    """compute_avg_description_encodings (SEG:324-337) on stacked description encodings: desc float16/float32 [n][dim],
+    offs int32 [n_classes + 1] -> normalised class means [n_classes][dim] in desc's dtype."""
+    if desc.dtype not in (torch.float16, torch.float32):
+        raise TypeError("description_means takes float16 or float32 encodings")
+    out = torch.empty((offs.shape[0] - 1, desc.shape[1]), dtype=desc.dtype, device=desc.device)
+    call("bff_description_means", _ptr(desc), _ptr(offs, i32), offs.shape[0] - 1, desc.shape[1],
+         1 if desc.dtype == torch.float16 else 0, _ptr(out))
     return out

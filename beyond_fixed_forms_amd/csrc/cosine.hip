@@ -16,7 +16,7 @@ using float4v = __attribute__((ext_vector_type(4))) float;
 
 __global__ __launch_bounds__(256) void cosine_gemm_f16_kernel(const _Float16 *__restrict__ a, int na,
                                                                const _Float16 *__restrict__ b, int nb, int dim,
-                                                               float *__restrict__ out)
+                                                               float *__restrict__ out, int norm_b)
 {
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int tile_j = blockIdx.x * 4 + wave;                 // 4 column tiles per block
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_kernel(const _Float16 *__
     // the four k-quarters of a row live in lanes r, r+16, r+32, r+48
     sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);
     sb += __shfl_xor(sb, 16); sb += __shfl_xor(sb, 32);
-    const float nbj = sqrtf(sb);                              // column j0 + (lane & 15)
+    const float nbj = norm_b ? sqrtf(sb) : 1.0f;              // column j0 + (lane & 15)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = kq * 4 + q;                           // C/D map: col = lane & 15, row = 4*(lane>>4) + q
@@ -53,6 +53,74 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_kernel(const _Float16 *__
     }
 }
 
+
+// The same product for MANY rows against a bank of <= a few hundred columns (BASELINE config 5: 9000 x 768 features
+// x 200 labels; the box filter of segmentation_2d.py:388-393 batched over all frames and queries): a block of 4 waves
+// owns 64 feature rows and a strip of kStrip = 96 bank columns that it stages ONCE, whole (<= 768 k), in LDS -- every
+// load of the strip is in flight at the same time (147 KB behind one barrier instead of 24 dependent L2 round
+// trips) -- and each wave then runs 6 MFMAs per 32-deep k-step out of LDS against its own A fragments, which come
+// straight from global memory (one 16-byte load per lane and step, read exactly once).  Row pitch 392 dwords: the
+// sixteen 16-byte fragment reads of a ds_read_b128 lane group start at distinct multiples of 4 banks.
+constexpr int kStripTiles = 6, kStrip = kStripTiles * 16, kStripK = 768, kStripPitch = kStripK + 16;   // halfs
+
+__global__ __launch_bounds__(256) void cosine_gemm_f16_strip_kernel(const _Float16 *__restrict__ a, int na,
+                                                                     const _Float16 *__restrict__ b, int nb, int dim,
+                                                                     float *__restrict__ out, int norm_b)
+{
+    extern __shared__ _Float16 s_dyn[];
+    _Float16 *sb = s_dyn;                                          // [kStrip][kStripPitch]
+    float *s_nb = reinterpret_cast<float *>(s_dyn + (size_t)kStrip * kStripPitch);     // [kStrip] sum of squares
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = (blockIdx.x * 4 + wave) * 16, j0 = blockIdx.y * kStrip;
+    const int r = lane & 15, kq = lane >> 4;
+    const bool ra = i0 + r < na;
+    const _Float16 *pa = a + (int64_t)(ra ? i0 + r : 0) * dim + 8 * kq;
+    float4v acc[kStripTiles];
+#pragma unroll
+    for (int t = 0; t < kStripTiles; ++t) acc[t] = (float4v){0.f, 0.f, 0.f, 0.f};
+    float sa = 0.f;
+    const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tid < kStrip) s_nb[tid] = 0.f;
+    for (int kc = 0; kc < dim; kc += kStripK) {                    // dims beyond 768: the strip is staged in pieces
+        const int kn = min(kStripK, dim - kc), segs = kn / 8;      // 16-byte segments per row
+        __syncthreads();                                           // previous piece fully consumed / s_nb zeroed
+        for (int sidx = tid; sidx < kStrip * segs; sidx += 256) {
+            const int row = sidx / segs, seg = sidx - row * segs;
+            half8 v = zero;
+            if (j0 + row < nb) v = *reinterpret_cast<const half8 *>(b + (int64_t)(j0 + row) * dim + kc + 8 * seg);
+            *reinterpret_cast<half8 *>(sb + (size_t)row * kStripPitch + 8 * seg) = v;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q = fmaf((float)v[e], (float)v[e], q);
+            atomicAdd(&s_nb[row], q);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k0 = 0; k0 < kn; k0 += 32) {
+            const half8 fa = ra ? *reinterpret_cast<const half8 *>(pa + kc + k0) : zero;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sa = fmaf((float)fa[e], (float)fa[e], sa);
+#pragma unroll
+            for (int t = 0; t < kStripTiles; ++t) {
+                const half8 fb = *reinterpret_cast<const half8 *>(sb + (size_t)(t * 16 + r) * kStripPitch + k0 + 8 * kq);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);           // the four k-quarters of a row: lanes r, r+16, r+32, r+48
+#pragma unroll
+    for (int t = 0; t < kStripTiles; ++t) {
+        const int j = j0 + t * 16 + r;                            // C/D map: col = lane & 15, row = 4 * (lane >> 4) + q
+        const float nbj = norm_b ? sqrtf(s_nb[t * 16 + r]) : 1.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = kq * 4 + q;
+            const float nai = sqrtf(__shfl(sa, row));
+            const int i = i0 + row;
+            if (i < na && j < nb) out[(int64_t)i * nb + j] = acc[t][q] / (nai * nbj);
+        }
+    }
+}
 
 // Cosine of every (a_i, b_j) pair IN THE DTYPE OF THE EMBEDDINGS, i.e. with the roundings of the reference's
 // tensor expression  (e1 @ e2.T) / (e1.norm() * e2.norm().T)  (compute_clip_similarity R:109-114): each of the
@@ -96,16 +164,42 @@ __global__ __launch_bounds__(256) void cosine_rows_kernel(const T *__restrict__ 
 
 using namespace bff;
 
+static int launch_cosine_gemm(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim, float *cos, int norm_b,
+                              void *stream, const char *what)
+{
+    BFF_REQUIRE(na >= 0 && nb >= 0 && dim > 0, "%s: bad sizes", what);
+    BFF_REQUIRE(dim % 32 == 0, "%s: dim must be a multiple of 32", what);
+    if (na == 0 || nb == 0) return BFF_OK;
+    BFF_REQUIRE(a && b && cos, "%s: null pointer", what);
+    if (na >= 64) {                                               // many rows: bank strips staged whole in LDS
+        static bool attr_set = false;
+        const size_t lds = sizeof(_Float16) * (size_t)kStrip * kStripPitch + sizeof(float) * kStrip;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_gemm_f16_strip_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail((int)e, "%s: LDS attribute: %s", what, hipGetErrorString(e));
+            attr_set = true;
+        }
+        dim3 grid((unsigned)ceil_div(na, 64), (unsigned)ceil_div(nb, kStrip));
+        cosine_gemm_f16_strip_kernel<<<grid, 256, lds, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b, nb,
+                                                                           dim, cos, norm_b);
+        return launched(what);
+    }
+    dim3 grid((unsigned)ceil_div(ceil_div(nb, 16), 4), (unsigned)ceil_div(na, 16));
+    cosine_gemm_f16_kernel<<<grid, 256, 0, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b, nb, dim, cos, norm_b);
+    return launched(what);
+}
+
 extern "C" int bff_cosine_gemm_f16(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim, float *cos,
                                    void *stream)
 {
-    BFF_REQUIRE(na >= 0 && nb >= 0 && dim > 0, "bff_cosine_gemm_f16: bad sizes");
-    BFF_REQUIRE(dim % 32 == 0, "bff_cosine_gemm_f16: dim must be a multiple of 32");
-    if (na == 0 || nb == 0) return BFF_OK;
-    BFF_REQUIRE(a && b && cos, "bff_cosine_gemm_f16: null pointer");
-    dim3 grid((unsigned)ceil_div(ceil_div(nb, 16), 4), (unsigned)ceil_div(na, 16));
-    cosine_gemm_f16_kernel<<<grid, 256, 0, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b, nb, dim, cos);
-    return launched("bff_cosine_gemm_f16");
+    return launch_cosine_gemm(a, na, b, nb, dim, cos, 1, stream, "bff_cosine_gemm_f16");
+}
+
+extern "C" int bff_normalized_gemm_f16(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim, float *sim,
+                                       void *stream)
+{
+    return launch_cosine_gemm(a, na, b, nb, dim, sim, 0, stream, "bff_normalized_gemm_f16");
 }
 
 extern "C" int bff_cosine_rows(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim, int32_t dtype,
@@ -121,4 +215,60 @@ extern "C" int bff_cosine_rows(const void *a, int32_t na, const void *b, int32_t
     else
         cosine_rows_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float *)a, na, (const float *)b, nb, dim, cos);
     return launched("bff_cosine_rows");
+}
+
+namespace bff {
+// one wave per class: lanes stride over dim (<= 64 * 32 = 2048), rows of the class one after the other
+template <typename T>
+__global__ __launch_bounds__(64) void description_means_kernel(const T *__restrict__ desc, const int32_t *__restrict__ offs,
+                                                                int dim, T *__restrict__ out)
+{
+    constexpr int kMax = 32;                                       // dim <= 2048
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int lo = offs[c], hi = offs[c + 1];
+    float mean[kMax];
+#pragma unroll
+    for (int q = 0; q < kMax; ++q) mean[q] = 0.f;
+    for (int row = lo; row < hi; ++row) {
+        const T *p = desc + (int64_t)row * dim;
+        float v[kMax], ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < kMax; ++q) {
+            const int k = lane + 64 * q;
+            v[q] = k < dim ? (float)p[k] : 0.f;
+            ss = fmaf(v[q], v[q], ss);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) ss += __shfl_xor(ss, d);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);        // F.normalize: x / max(||x||, eps)
+#pragma unroll
+        for (int q = 0; q < kMax; ++q) mean[q] += v[q] * inv;
+    }
+    const float cnt = (float)(hi - lo);
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMax; ++q) { mean[q] = mean[q] / cnt; ss = fmaf(mean[q], mean[q], ss); }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ss += __shfl_xor(ss, d);
+    const float nrm = sqrtf(ss);
+#pragma unroll
+    for (int q = 0; q < kMax; ++q) {
+        const int k = lane + 64 * q;
+        if (k < dim) out[(int64_t)c * dim + k] = (T)(mean[q] / nrm);
+    }
+}
+}  // namespace bff
+
+extern "C" int bff_description_means(const void *desc, const int32_t *offs, int32_t n_classes, int32_t dim, int32_t dtype,
+                                     void *out, void *stream)
+{
+    BFF_REQUIRE(n_classes >= 0 && dim > 0 && (dtype == 0 || dtype == 1), "bff_description_means: bad arguments");
+    BFF_LIMIT(dim <= 2048, "bff_description_means: dim > 2048");
+    if (n_classes == 0) return BFF_OK;
+    BFF_REQUIRE(desc && offs && out, "bff_description_means: null pointer");
+    if (dtype == 1)
+        description_means_kernel<_Float16><<<n_classes, 64, 0, as_stream(stream)>>>((const _Float16 *)desc, offs, dim, (_Float16 *)out);
+    else
+        description_means_kernel<float><<<n_classes, 64, 0, as_stream(stream)>>>((const float *)desc, offs, dim, (float *)out);
+    return launched("bff_description_means");
 }

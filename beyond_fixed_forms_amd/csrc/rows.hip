@@ -85,8 +85,17 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
                                                               const int32_t *__restrict__ ia, int na,
                                                               const uint64_t *__restrict__ b,
                                                               const int32_t *__restrict__ ib, int nb, int64_t nw,
-                                                              int64_t k_split, int32_t *__restrict__ inter)
+                                                              int64_t k_split, int32_t *__restrict__ inter,
+                                                              const int32_t *__restrict__ k_dev, int lim_a, int hole_hi)
 {
+    // k_dev (optional): only the first *k_dev rows of a (when lim_a) resp. of b's leading block [0, hole_hi) hold data,
+    // the rest of those ranges is all zero: tiles that lie entirely in the zero part are skipped (the output is
+    // zeroed by the host when the words are split over z; callers never read the skipped entries otherwise)
+    if (k_dev) {
+        const int kd = *k_dev;
+        if (lim_a && (int)blockIdx.y * kT >= kd) return;
+        if ((int)blockIdx.x * kT >= kd && (int)(blockIdx.x + 1) * kT <= hole_hi) return;
+    }
     // blockIdx.z owns the word range [z*k_split, (z+1)*k_split): small row counts still fill the chip.
     // Partial counts are combined with integer atomics (exact, order independent) into a zeroed matrix.
     __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
@@ -1069,7 +1078,7 @@ __global__ void permute_bits_kernel(const uint64_t *__restrict__ in, int64_t nw_
 
 // ---- group OR / confidence mean ---------------------------------------------------------------
 constexpr int kOrSplit = 32;      // members per block along z
-constexpr int kFuseMax = 64;      // rows of the fused overlap pass = groups the device forms by itself
+constexpr int kFuseMax = 256;     // rows of the fused overlap pass = groups the device forms by itself
 
 // Sequential mean of one group's confidences by the first wave of the calling block: all its lanes gather
 // 1024 confidences into LDS at once (the gathers are the slow part), then lane 0 runs the strictly sequential
@@ -1216,24 +1225,55 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restr
     }
 }
 
-// members of group g in ascending row order: one wave per group walks comp[] 64 rows at a time
+// members of group g in ascending row order: one block per group walks comp[] 256 rows at a time (ballot per wave,
+// the four waves' counts meet in LDS)
 __global__ __launch_bounds__(256) void group_members_kernel(const int32_t *__restrict__ comp, int n,
                                                              const int32_t *__restrict__ info, int cap,
                                                              const int32_t *__restrict__ first,
                                                              const int32_t *__restrict__ offs,
                                                              int32_t *__restrict__ members)
 {
-    const int lane = lane_id();
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ int wcnt[2][4];
+    const int g = blockIdx.x;
     if (g >= min(info[0], cap)) return;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int root = first[g];
-    int base = offs[g];
-    for (int i0 = 0; i0 < n; i0 += kWave) {
-        const int i = i0 + lane;
+    int base = offs[g], it = 0;
+    for (int i0 = 0; i0 < n; i0 += 256, it ^= 1) {
+        const int i = i0 + threadIdx.x;
         const bool m = i < n && comp[i] == root;
         const uint64_t bal = __ballot(m);
-        if (m) members[base + __popcll(bal & ((1ull << lane) - 1))] = i;
-        base += __popcll(bal);
+        if (lane == 0) wcnt[it][wave] = __popcll(bal);
+        __syncthreads();                                   // double-buffered counters: one barrier per step
+        int before = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int c = wcnt[it][q]; total += c; if (q < wave) before += c; }
+        if (m) members[base + before + __popcll(bal & ((1ull << lane) - 1))] = i;
+        base += total;
+    }
+}
+
+// Undo the spatial point sort by SCATTER: out[r] bit perm[s] = in[r] bit s for the set bits only (aggregated rows
+// hold a few percent of the points, so this touches ~1/50 of what a bit gather per output point reads).  out must be
+// zero; perm[s] = original index of sorted position s.  Rows >= *k_dev (when given) are skipped.
+__global__ __launch_bounds__(256) void scatter_bits_kernel(const uint64_t *__restrict__ in, int64_t nw_in,
+                                                            const int32_t *__restrict__ perm, int64_t n,
+                                                            int64_t nw_out, uint64_t *__restrict__ out,
+                                                            const int32_t *__restrict__ k_dev)
+{
+    const int r = blockIdx.y;
+    if (k_dev && r >= *k_dev) return;
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw_in) return;
+    uint64_t v = in[(int64_t)r * nw_in + w];
+    while (v) {
+        const int b = __ffsll((unsigned long long)v) - 1;
+        v &= v - 1;
+        const int64_t s = w * 64 + b;
+        if (s < n) {
+            const int o = perm[s];
+            atomicOr((unsigned long long *)(out + (int64_t)r * nw_out + (o >> 6)), 1ull << (o & 63));
+        }
     }
 }
 
@@ -1336,37 +1376,39 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
         k = kd;
     }
     constexpr int kPitch = kWave + 1;                        // column- and row-wise LDS accesses both conflict-free
-    __shared__ unsigned long long s_mask[kFuseMax];          // row i -> rows j > i that overlap it
+    constexpr int kMW = kFuseMax / 64;                       // 64-bit words of a row's pair mask
+    __shared__ unsigned long long s_mask[kFuseMax][kMW];     // row i -> rows j > i that overlap it
     __shared__ int s_size[kFuseMax];
     extern __shared__ uint64_t s_dyn[];
     uint64_t *s_col = s_dyn;                                 // [k][kPitch]
-    int32_t *s_int = reinterpret_cast<int32_t *>(s_dyn + (size_t)k * kPitch);   // [k][k]
     const int t = threadIdx.x;
     const int64_t w = (int64_t)blockIdx.x * kWave + t;
-    // independent loads, several in flight: the intersections, then this thread's word of every row
-#pragma unroll 8
-    for (int q = t; q < k * k; q += kWave) s_int[q] = inter[(q / k) * stride + (q % k)];
+    const int kw = (k + 63) / 64;
+    // independent loads, several in flight: this thread's word of every row, then the pair flags (from the
+    // intersections BEFORE any edit, P:289-292) as ballots straight out of global memory
 #pragma unroll 8
     for (int r = 0; r < k; ++r) s_col[r * kPitch + t] = w < nw ? rows[(int64_t)r * nw + w] : 0;
-    if (t < k) s_size[t] = size[t];
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // single wave: its LDS ops complete in order
-    for (int i = 0; i < k; ++i) {
-        const int v = t < k ? s_int[i * k + t] : 0;
-        const unsigned long long m = __ballot(v > 0 && t > i);
-        if (t == 0) s_mask[i] = m;
-        if (t == i && blockIdx.x == 0) before[i] = v;         // popcount of the row before any edit (P:592)
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int i = 0; i < k; ++i) {
-        unsigned long long m = s_mask[i];                     // wave-uniform
-        while (m) {
-            const int j = __ffsll(m) - 1;
-            m &= m - 1;
-            const bool i_wins = s_size[i] > s_size[j];        // ties: i loses (P:296-299)
-            const int d = i_wins ? j : i, sr = i_wins ? i : j;
-            s_col[d * kPitch + t] &= ~s_col[sr * kPitch + t];
+    for (int r = t; r < k; r += kWave) s_size[r] = size[r];
+    for (int i = 0; i < k; ++i)
+        for (int q = 0; q < kw; ++q) {
+            const int j = 64 * q + t;
+            const int v = j < k ? inter[(int64_t)i * stride + j] : 0;
+            const unsigned long long m = __ballot(v > 0 && j > i);
+            if (t == 0) s_mask[i][q] = m;
+            if (j == i && blockIdx.x == 0) before[i] = v;     // popcount of the row before any edit (P:592)
         }
-    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // single wave: its LDS ops complete in order
+    for (int i = 0; i < k; ++i)
+        for (int q = 0; q < kw; ++q) {
+            unsigned long long m = s_mask[i][q];              // wave-uniform
+            while (m) {
+                const int j = 64 * q + __ffsll(m) - 1;
+                m &= m - 1;
+                const bool i_wins = s_size[i] > s_size[j];    // ties: i loses (P:296-299)
+                const int d = i_wins ? j : i, sr = i_wins ? i : j;
+                s_col[d * kPitch + t] &= ~s_col[sr * kPitch + t];
+            }
+        }
     const uint64_t kp = keep ? (w < nw ? keep[w] : 0) : ~0ull;
     for (int r = 0; r < k; ++r) {
         const uint64_t v = s_col[r * kPitch + t] & kp;
@@ -1374,11 +1416,11 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
         if (w < nw) rows[(int64_t)r * nw + w] = v;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (t < k) {                                              // lane r adds up row r over the block's 64 columns
+    for (int r = t; r < k; r += kWave) {                      // lane adds up rows r, r + 64, ... over the block's 64 columns
         int pc = 0;
 #pragma unroll 8
-        for (int c = 0; c < kWave; ++c) pc += popc64(s_col[t * kPitch + c]);
-        if (pc) atomicAdd(after + t, pc);
+        for (int c = 0; c < kWave; ++c) pc += popc64(s_col[r * kPitch + c]);
+        if (pc) atomicAdd(after + r, pc);
     }
 }
 
@@ -1532,6 +1574,19 @@ __global__ void rle_lengths_kernel(int64_t *__restrict__ counts, int64_t n_runs_
 
 using namespace bff;
 
+// dynamic LDS beyond 64 KB has to be enabled per kernel once
+static int resolve_lds_attr(size_t bytes, const char *what)
+{
+    static size_t enabled = 0;
+    if (bytes <= enabled || bytes <= 64 * 1024) return BFF_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resolve_overlaps_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * kFuseMax * (kWave + 1)));
+    if (e != hipSuccess) return fail((int)e, "%s: LDS attribute: %s", what, hipGetErrorString(e));
+    enabled = sizeof(uint64_t) * kFuseMax * (kWave + 1);
+    return BFF_OK;
+}
+#define BFF_TRY_LDS(bytes, what) do { const int rc_ = resolve_lds_attr((bytes), (what)); if (rc_ != BFF_OK) return rc_; } while (0)
+
 extern "C" int bff_popcount_rows(const uint64_t *rows, const int32_t *idx, int32_t n_rows, int64_t nw,
                                  int32_t *area, void *stream)
 {
@@ -1560,8 +1615,31 @@ extern "C" int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t 
         if (e != hipSuccess) return fail((int)e, "bff_cross_popcount: memset: %s", hipGetErrorString(e));
     }
     dim3 grid((unsigned)ceil_div(nb, kT), (unsigned)ceil_div(na, kT), (unsigned)nz);
-    cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, ia, na, b, ib, nb, nw, k_split, inter);
+    cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, ia, na, b, ib, nb, nw, k_split, inter, nullptr, 0, 0);
     return launched("bff_cross_popcount");
+}
+
+// bff_cross_popcount where only the first *k_dev rows of the leading `lead` rows of b (and, with limit_a != 0, of a)
+// are non-zero: tiles inside the zero part are skipped.  inter is zeroed first.
+extern "C" int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint64_t *b, int32_t nb, int64_t nw,
+                                      int32_t *inter, const int32_t *k_dev, int32_t limit_a, int32_t lead, void *stream)
+{
+    BFF_REQUIRE(na >= 0 && nb >= 0 && nw >= 0 && lead >= 0 && lead <= nb, "bff_cross_popcount_dev: bad sizes");
+    if (na == 0 || nb == 0) return BFF_OK;
+    BFF_REQUIRE(a && b && inter && k_dev, "bff_cross_popcount_dev: null pointer");
+    const int64_t tiles = ceil_div(nb, kT) * ceil_div(na, kT);
+    int64_t k_split = nw;
+    if (tiles < 512) {
+        k_split = ceil_div(ceil_div(nw * tiles, 512), kKW) * kKW;
+        if (k_split < 2 * kKW) k_split = 2 * kKW;
+    }
+    const int64_t nz = ceil_div(nw, k_split);
+    hipError_t e = hipMemsetAsync(inter, 0, sizeof(int32_t) * (size_t)na * nb, as_stream(stream));
+    if (e != hipSuccess) return fail((int)e, "bff_cross_popcount_dev: memset: %s", hipGetErrorString(e));
+    dim3 grid((unsigned)ceil_div(nb, kT), (unsigned)ceil_div(na, kT), (unsigned)(nz > 0 ? nz : 1));
+    cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, nullptr, na, b, nullptr, nb, nw, k_split, inter, k_dev,
+                                                              limit_a, lead);
+    return launched("bff_cross_popcount_dev");
 }
 
 extern "C" int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *area, int32_t *mean_word,
@@ -1783,8 +1861,8 @@ extern "C" int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const
     BFF_REQUIRE(rows && inter && size && before && after, "bff_resolve_overlaps: null pointer");
     hipError_t e = hipMemsetAsync(after, 0, sizeof(int32_t) * (size_t)k, as_stream(stream));
     if (e != hipSuccess) return fail((int)e, "bff_resolve_overlaps: memset: %s", hipGetErrorString(e));
-    resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave,
-                              sizeof(uint64_t) * (size_t)k * (kWave + 1) + sizeof(int32_t) * (size_t)k * k,
+    BFF_TRY_LDS(sizeof(uint64_t) * (size_t)k * (kWave + 1), "bff_resolve_overlaps");
+    resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave, sizeof(uint64_t) * (size_t)k * (kWave + 1),
                               as_stream(stream)>>>(rows, nw, k, inter, k, size, keep, before, after, nullptr);
     return launched("bff_resolve_overlaps");
 }
@@ -1798,8 +1876,8 @@ extern "C" int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t n
     BFF_REQUIRE(rows && inter && size && before && after && k_dev, "bff_resolve_overlaps_dev: null pointer");
     hipError_t e = hipMemsetAsync(after, 0, sizeof(int32_t) * (size_t)k_cap, as_stream(stream));
     if (e != hipSuccess) return fail((int)e, "bff_resolve_overlaps_dev: memset: %s", hipGetErrorString(e));
-    resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave,
-                              sizeof(uint64_t) * (size_t)k_cap * (kWave + 1) + sizeof(int32_t) * (size_t)k_cap * k_cap,
+    BFF_TRY_LDS(sizeof(uint64_t) * (size_t)k_cap * (kWave + 1), "bff_resolve_overlaps_dev");
+    resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave, sizeof(uint64_t) * (size_t)k_cap * (kWave + 1),
                               as_stream(stream)>>>(rows, nw, k_cap, inter, k_cap, size, keep, before, after, k_dev);
     return launched("bff_resolve_overlaps_dev");
 }
@@ -1920,7 +1998,7 @@ extern "C" int bff_group_components(const int32_t *comp, const int32_t *area, in
     group_scan_kernel<<<1, 1024, 0, st>>>(comp, count, area, n_rows, iou_thres, min_members, cap, info, sizes, first, offs,
                                          slices, bff_group_slice_cap(n_rows, cap));
     if (n_rows > 0)
-        group_members_kernel<<<(unsigned)ceil_div(cap, 4), 256, 0, st>>>(comp, n_rows, info, cap, first, offs, members);
+        group_members_kernel<<<(unsigned)cap, 256, 0, st>>>(comp, n_rows, info, cap, first, offs, members);
     return launched("bff_group_components");
 }
 
@@ -1947,4 +2025,16 @@ extern "C" int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n
         or_reduce_grouped_kernel<float><<<grid, 256, 0, st>>>(rows, nw, info, cap, offs, members, slices, slice_cap, out,
                                                              (const float *)conf, (float *)conf_mean);
     return launched("bff_or_reduce_grouped");
+}
+
+extern "C" int bff_scatter_bits(const uint64_t *rows_in, int32_t n_rows, int64_t nw_in, const int32_t *perm, int64_t n,
+                                int64_t nw_out, uint64_t *rows_out, const int32_t *k_dev, void *stream)
+{
+    BFF_REQUIRE(n_rows >= 0 && n >= 0 && nw_out == ceil_div(n, 64) && nw_in >= 0, "bff_scatter_bits: bad sizes");
+    if (n_rows == 0 || n == 0 || nw_in == 0) return BFF_OK;
+    BFF_REQUIRE(rows_in && perm && rows_out, "bff_scatter_bits: null pointer");
+    BFF_LIMIT(n_rows <= 65535, "bff_scatter_bits: too many rows");
+    dim3 grid((unsigned)ceil_div(nw_in, 256), (unsigned)n_rows);
+    scatter_bits_kernel<<<grid, 256, 0, as_stream(stream)>>>(rows_in, nw_in, perm, n, nw_out, rows_out, k_dev);
+    return launched("bff_scatter_bits");
 }

@@ -110,12 +110,14 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     // path (more groups than the device forms), which reads the rows again and clears them itself
     BFF_TRY(bff_clear_flagged_chunks_unless(ws->rows, n_rows, nw, ws->chunk_mask, info + 1, stream));
     // a16 + P:592-596: intersections before any edit, ordered overlap decisions, &= keep, both popcounts
-    BFF_TRY(bff_cross_popcount(ws->agg, nullptr, cap, ws->agg, nullptr, cap, nw, ws->inter, stream));
+    BFF_TRY(bff_cross_popcount_dev(ws->agg, cap, ws->agg, cap, nw, ws->inter, info, 1, cap, stream));
     BFF_TRY(bff_resolve_overlaps_dev(ws->agg, cap, nw, ws->inter, hdr + BFF_HDR_SIZES, ws->keep, hdr + BFF_HDR_BEFORE,
                                      hdr + BFF_HDR_AFTER, info, stream));
-    // caller's point order; the refinement's first device pass (R:186-217) rides along when stage 1 is resident
-    if (sc->unsort) {
-        BFF_TRY(bff_permute_bits(ws->agg, cap, nw, sc->unsort, n, nw, ws->both, stream));
+    // caller's point order (scatter of the set bits); the refinement's first device pass (R:186-217) rides along when
+    // stage 1 is resident
+    if (sc->perm) {
+        BFF_ZERO(ws->both, sizeof(uint64_t) * (size_t)cap * nw);
+        BFF_TRY(bff_scatter_bits(ws->agg, cap, nw, sc->perm, n, nw, ws->both, info, stream));
     } else {
         e = hipMemcpyAsync(ws->both, ws->agg, sizeof(uint64_t) * (size_t)cap * nw, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return fail((int)e, "bff_scene_project: copy: %s", hipGetErrorString(e));
@@ -123,8 +125,8 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     if (sc->s1_rows > 0) {
         uint64_t *s1 = ws->both + (size_t)cap * nw;
         BFF_TRY(bff_rle_to_rows(sc->s1_run_start, sc->s1_run_end, sc->s1_row_run_offs, sc->s1_rows, n, nw, s1, stream));
-        BFF_TRY(bff_cross_popcount(s1, nullptr, sc->s1_rows, ws->both, nullptr, cap + sc->s1_rows, nw,
-                                   hdr + BFF_HDR_CROSS, stream));
+        BFF_TRY(bff_cross_popcount_dev(s1, sc->s1_rows, ws->both, cap + sc->s1_rows, nw, hdr + BFF_HDR_CROSS, info, 0, cap,
+                                       stream));
     }
     e = hipMemcpyAsync(ws->hdr_host, hdr, sizeof(int32_t) * (size_t)bff_scene_header_words(sc->s1_rows),
                        hipMemcpyDeviceToHost, st);

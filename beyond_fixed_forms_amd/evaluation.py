@@ -1,14 +1,24 @@
-"""The consumer right after the hot path: prediction <-> ground-truth overlap counting of the ScanNet instance
-evaluation (reference evaluation/eval/scannetv2_inst_eval.py:265-349, `assign_instances_for_scan`), on the
-bit-row primitives.  Only the O(P x G x N) counting is done here; the AP bookkeeping around it (matching,
-confidence sorting, precision/recall curves) is unchanged host logic and stays in the reference's evaluator.
+"""The consumer right after the hot path: ScanNet instance evaluation's prediction <->
+ground-truth assignment, reference evaluation/eval/scannetv2_inst_eval.py:265-365 (`assign_instances_for_scan`) with
+instance_eval_util.py:158-174 (`get_instances`), on the bit-row primitives.
+
+The reference counts, pair by pair, `np.count_nonzero(np.logical_and(gts == instance_id, pred_mask))` over N points
+(O(P x G x N) byte operations per scene); here the predicted masks and the ground-truth instances are bit rows on
+the device and ONE popcount Gram (bff_cross_popcount) delivers every intersection, the void intersections and the
+vertex counts; the host then assembles the reference's nested dicts in the reference's order.  The AP curves built
+from these dicts (evaluate_matches, :62-214) are unchanged host logic and stay in the reference's evaluator.
 """
 from __future__ import annotations
+
+from copy import deepcopy
 
 import numpy as np
 import torch
 
 from . import _lib
+
+MIN_REGION_SIZE = {"stpls3d": 10}        # scannetv2_inst_eval.py:42-45 (everything else: 100)
+SEM_OFFSET = {"scannetv2": 2, "scannet200": 2, "replica": 1, "stpls3d": 1, "scannetpp": 105}     # :270-281
 
 
 def pred_gt_overlaps(pred_rows: torch.Tensor, gts: torch.Tensor, instance_ids, void_mask=None):
@@ -32,3 +42,121 @@ def pred_gt_overlaps(pred_rows: torch.Tensor, gts: torch.Tensor, instance_ids, v
         out.append(_lib.cross_popcount(pred_rows, void_rows))
     res = _lib.fetch(*out)
     return res[0], res[1], res[2], (res[3][:, 0] if void_mask is not None else None)
+
+
+def encode_gt(gts_sem, gts_ins, dataset_name="scannet200"):
+    """:270-291: shift the semantic ids of the dataset, clamp negatives, `sem * encode_value + (ins + 1)`, 0 where the
+    instance id is ignored.  Returns (gts int array [N], encode_value)."""
+    encode = 10000 if dataset_name == "scannetpp" else 1000                       # :23-27
+    sem = np.array(gts_sem) - SEM_OFFSET.get(dataset_name, 0) + 1
+    sem[sem < 0] = 0
+    ins = np.array(gts_ins) + 1
+    gts = sem * encode + ins
+    gts[ins < 0] = 0
+    return gts, encode
+
+
+def assign_instances_for_scan(preds, gts_sem, gts_ins, class_labels, use_label=True, dataset_name="scannet200",
+                              device="cuda", pred_rows=None):
+    """ScanNetEval.assign_instances_for_scan (:265-365) -> (gt2pred, pred2gt), the same nested dicts.
+
+    preds: list of {"scan_id", "label_id", "conf", "pred_mask"}; pred_mask is an (N,) array (anything != 0 is set),
+    or ignored when `pred_rows` (int64 bit rows [len(preds)][nw] on the device, e.g. FinalResult.rows) is given.
+    class_labels: the evaluator's valid_class_labels (ids 1..len)."""
+    _lib.load()
+    dev = torch.device(device)
+    labels = list(class_labels)
+    valid_ids = np.arange(len(labels)) + 1                                        # :30
+    id2label = {int(i): lab for i, lab in zip(valid_ids, labels)}
+    eval_labels = labels if use_label else ["class_agnostic"]                     # :55-58
+    gts, encode = encode_gt(gts_sem, gts_ins, dataset_name)
+    n = gts.shape[0]
+    min_region = MIN_REGION_SIZE.get(dataset_name, 100)
+
+    # ---- ground-truth instances (get_instances): ascending id, id 0 skipped, only valid classes
+    inst_ids = np.unique(gts)
+    inst_ids = inst_ids[inst_ids != 0]
+    gts_dev = torch.from_numpy(np.ascontiguousarray(gts, dtype=np.int64)).to(dev)
+    # ---- predictions that reach the counting stage (label known)
+    keep = []
+    for k, pred in enumerate(preds):
+        if use_label and pred["label_id"] not in id2label:                        # :311-312
+            continue
+        keep.append(k)
+    if pred_rows is None:
+        if keep:
+            dense = torch.from_numpy(np.stack([np.not_equal(np.asarray(preds[k]["pred_mask"]), 0) for k in keep]))
+            for k in keep:
+                assert np.asarray(preds[k]["pred_mask"]).shape[0] == n            # :320
+            rows = _lib.pack_rows(dense.to(dev).contiguous())
+        else:
+            rows = torch.zeros((0, (n + 63) // 64), dtype=torch.int64, device=dev)
+    else:
+        rows = _lib.gather_rows(pred_rows, torch.tensor(keep, dtype=torch.int32, device=dev)) if keep else pred_rows[:0]
+    bool_void = np.logical_not(np.in1d(gts // encode, valid_ids))                 # :306
+    if len(keep) and len(inst_ids):
+        inter, pred_count, gt_count, void_inter = pred_gt_overlaps(rows, gts_dev, inst_ids, bool_void)
+    else:
+        gt_rows = _lib.ids_to_rows(gts_dev, torch.from_numpy(inst_ids.astype(np.int64)).to(dev)) if len(inst_ids) else None
+        gt_count = _lib.popcount_rows(gt_rows).cpu().numpy() if gt_rows is not None else np.zeros(0, np.int32)
+        if len(keep):
+            void_rows = _lib.pack_rows(torch.from_numpy(bool_void).to(dev).reshape(1, -1).contiguous())
+            pred_count = _lib.popcount_rows(rows).cpu().numpy()
+            void_inter = _lib.cross_popcount(rows, void_rows).cpu().numpy()[:, 0]
+        else:
+            pred_count = void_inter = np.zeros(0, np.int32)
+        inter = np.zeros((len(keep), len(inst_ids)), np.int32)
+
+    gt_instances = {lab: [] for lab in labels}
+    col_of = {}                                                                    # (label, position) -> Gram column
+    for c, iid in enumerate(inst_ids):
+        label_id = int(iid // encode)
+        if label_id in id2label:
+            lab = id2label[label_id]
+            col_of[(lab, len(gt_instances[lab]))] = c
+            gt_instances[lab].append({"instance_id": int(iid), "label_id": label_id, "vert_count": int(gt_count[c]),
+                                      "med_dist": -1, "dist_conf": 0.0, "box": np.zeros((6))})
+    if use_label:                                                                  # :294-298
+        gt2pred = deepcopy(gt_instances)
+        for lab in gt2pred:
+            for gt in gt2pred[lab]:
+                gt["matched_pred"] = []
+        cols = {lab: [col_of[(lab, k)] for k in range(len(v))] for lab, v in gt2pred.items()}
+    else:                                                                          # :300-308
+        agnostic, acols = [], []
+        for lab, instances in gt_instances.items():
+            agnostic += deepcopy(instances)
+            acols += [col_of[(lab, k)] for k in range(len(instances))]
+        for gt in agnostic:
+            gt["matched_pred"] = []
+        gt2pred = {eval_labels[0]: agnostic}
+        cols = {eval_labels[0]: acols}
+
+    pred2gt = {lab: [] for lab in eval_labels}
+    num_pred_instances = 0
+    for r, k in enumerate(keep):                                                   # :309-363
+        pred = preds[k]
+        label_name = id2label[pred["label_id"]] if use_label else eval_labels[0]
+        num = int(pred_count[r])
+        if num < min_region:                                                       # :323-324
+            continue
+        pred_instance = {"filename": "{}_{}".format(pred["scan_id"], num_pred_instances), "pred_id": num_pred_instances,
+                         "label_id": pred["label_id"] if use_label else None, "vert_count": num,
+                         "confidence": pred["conf"], "void_intersection": int(void_inter[r])}
+        matched_gt = []
+        for gt_num, gt_inst in enumerate(gt2pred[label_name]):
+            intersection = int(inter[r, cols[label_name][gt_num]])
+            if intersection > 0:
+                gt_copy = gt_inst.copy()
+                pred_copy = pred_instance.copy()
+                gt_copy["intersection"] = intersection
+                pred_copy["intersection"] = intersection
+                iou = float(intersection) / (gt_copy["vert_count"] + pred_copy["vert_count"] - intersection)
+                gt_copy["iou"] = iou
+                pred_copy["iou"] = iou
+                matched_gt.append(gt_copy)
+                gt2pred[label_name][gt_num]["matched_pred"].append(pred_copy)
+        pred_instance["matched_gt"] = matched_gt
+        num_pred_instances += 1
+        pred2gt[label_name].append(pred_instance)
+    return gt2pred, pred2gt

@@ -210,6 +210,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
     xyz = torch.empty((3, n_pad), dtype=torch.float64, device=dev)
     unsort = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     sort = n > 1
+    perm = None
     if n:
         perm = torch.empty(n, dtype=torch.int32, device=dev)
         codes = torch.empty(2 * n, dtype=torch.int32, device=dev)
@@ -255,7 +256,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
         frame_flags=f_flags_d, n_frames=nf, n_mask_frames=n_mask_frames, n_viewed=len(viewed), word_bits=word_bits,
         n_rows=row, run_start=run_start, run_end=run_end, mask_run_offs=run_offs, view_mask_offs=vmo_d, conf=conf_d,
         labels=labels, label_id=label_d, n_label_ids=max(1, len(ids)), stage1=getattr(scene, "stage1", None),
-        unsort=unsort[:n] if sort else None)
+        unsort=unsort[:n] if sort else None, perm=perm if sort else None)
 
 
 _taps = {}

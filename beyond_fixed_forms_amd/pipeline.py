@@ -15,9 +15,9 @@ import torch
 
 from . import _lib
 
-GROUP_CAP = 64
+GROUP_CAP = 256
 HDR_K, HDR_NUNIQUE, HDR_THR = 0, 4, 5
-HDR_SIZES, HDR_FIRST, HDR_BEFORE, HDR_AFTER, HDR_CONF, HDR_CROSS = 16, 80, 144, 208, 272, 336
+HDR_SIZES, HDR_FIRST, HDR_BEFORE, HDR_AFTER, HDR_CONF, HDR_CROSS = (16 + k * GROUP_CAP for k in range(6))
 
 
 class SceneStruct(ctypes.Structure):
@@ -27,7 +27,7 @@ class SceneStruct(ctypes.Structure):
                 ("depth_index", c_void_p), ("frame_mask", c_void_p), ("frame_rowbase", c_void_p),
                 ("frame_nmask", c_void_p), ("frame_flags", c_void_p),
                 ("run_start", c_void_p), ("run_end", c_void_p), ("mask_run_offs", c_void_p), ("view_mask_offs", c_void_p),
-                ("conf", c_void_p), ("label_id", c_void_p), ("unsort", c_void_p),
+                ("conf", c_void_p), ("label_id", c_void_p), ("unsort", c_void_p), ("perm", c_void_p),
                 ("s1_run_start", c_void_p), ("s1_run_end", c_void_p), ("s1_row_run_offs", c_void_p),
                 ("height", c_int32), ("width", c_int32), ("n_frames", c_int32), ("n_mviews", c_int32),
                 ("word_bits", c_int32), ("n_rows", c_int32), ("conf_f16", c_int32), ("n_label_ids", c_int32),
@@ -80,7 +80,9 @@ def scene_struct(ds, stage1=None, n_frames=None):
     for k in ("depth_index", "frame_mask", "frame_rowbase", "frame_nmask", "frame_flags", "run_start", "run_end",
               "mask_run_offs", "view_mask_offs", "label_id"):
         setattr(s, k, _p(getattr(ds, k)))
-    s.conf, s.unsort = _p(ds.conf), _p(ds.unsort)
+    s.conf, s.unsort, s.perm = _p(ds.conf), _p(ds.unsort), _p(ds.perm)
+    if ds.unsort is not None and ds.perm is None:
+        raise ValueError("a spatially sorted scene needs its inverse permutation (DeviceScene.perm)")
     s.height, s.width = ds.height, ds.width
     s.n_frames = ds.n_frames if n_frames is None else n_frames
     s.n_mviews = ds.view_mask_offs.shape[0] - 1

@@ -405,6 +405,7 @@ def _projection_back(fr: _Front, timers, phases, stage1=None) -> Stage2Result:
             _t[0] = now
 
     ds, cfg, dbg, debug_out = fr.ds, fr.cfg, fr.dbg, fr.debug_out
+    dbg.setdefault("path", "step")
     dev = ds.xyz.device
     n = ds.n_points
     rows, masked, viewed, keep, do_ratio = fr.rows, fr.masked, fr.viewed, fr.keep, fr.do_ratio

@@ -113,6 +113,7 @@ class DeviceScene:
     stage1: Optional[dict] = None
     unsort: Optional[torch.Tensor] = None   # i32 [N]: position of original point o in the sorted cloud (None = unsorted)
     tile_bounds: Optional[torch.Tensor] = None   # f64 [tiles][6]: boxes of the sweep's point tiles (frustum culling)
+    perm: Optional[torch.Tensor] = None     # i32 [N]: original index of sorted position s (inverse of `unsort`)
 
 
 def viewed_frame_ids(color_files, downsample_ratio):
@@ -132,7 +133,7 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True)
     nw = (n + 63) // 64
     n_pad = max(1024, ((n + 1023) // 1024) * 1024)
     soa = np.zeros((3, n_pad), dtype=np.float64)
-    unsort = None
+    unsort = perm = None
     if sort_points and n > 1:
         perm = morton_order(pts)                    # sorted position s holds original point perm[s]
         soa[:, :n] = pts[perm].T
@@ -255,4 +256,5 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True)
         run_start=t(rs, torch.int32), run_end=t(re, torch.int32), mask_run_offs=t(roffs, torch.int32),
         view_mask_offs=t(np.array(view_mask_offs, np.int32), torch.int32),
         conf=conf.to(dev), labels=labels, label_id=t(label_id, torch.int32), n_label_ids=max(1, len(ids)),
-        stage1=getattr(scene, "stage1", None), unsort=None if unsort is None else t(unsort, torch.int32))
+        stage1=getattr(scene, "stage1", None), unsort=None if unsort is None else t(unsort, torch.int32),
+        perm=None if perm is None else t(perm.astype(np.int32), torch.int32))

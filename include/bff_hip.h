@@ -353,6 +353,15 @@ int bff_argsort_i64(const int64_t *keys, int64_t *keys_scratch, int32_t *order_o
  * dim % 32 == 0, cos: float32 [na][nb]. */
 int bff_cosine_gemm_f16(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim,
                         float *cos, void *stream);
+/* a24 -- the box filter's product  F.normalize(box_emb) @ text.T  (SEG:388-393): rows of a are normalised, rows of b
+ * are taken as they are (the reference normalises the text mean beforehand, SEG:336).  Same kernels, same limits. */
+int bff_normalized_gemm_f16(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim,
+                            float *sim, void *stream);
+/* a24 -- compute_avg_description_encodings (SEG:324-337): per class c, rows [offs[c], offs[c+1]) of desc (float16 or
+ * float32 [n][dim]) are L2-normalised (eps 1e-12 as F.normalize), averaged, and the mean is normalised again;
+ * out: same dtype [n_classes][dim]; float32 arithmetic. */
+int bff_description_means(const void *desc, const int32_t *offs, int32_t n_classes, int32_t dim, int32_t dtype,
+                          void *out, void *stream);
 
 /* a21 -- the per-class text cosines in the dtype of the embeddings: cos[i][j] with every tensor op of
  *   (e1 @ e2.T) / (e1.norm() * e2.norm().T)  (compute_clip_similarity R:109-114) rounded to that dtype, so that
@@ -366,7 +375,7 @@ int bff_cosine_rows(const void *a, int32_t na, const void *b, int32_t nb, int32_
 /* ------------------------------------------------------------------------------------------
  * Groups formed on the device (P:203-226 without the host round trip) and the whole scene in one call.
  */
-#define BFF_GROUP_CAP 64          /* groups the device forms by itself (= rows of the fused overlap pass) */
+#define BFF_GROUP_CAP 256         /* groups the device forms by itself (= rows of the fused overlap pass) */
 #define BFF_SIGNATURE_BITS 30     /* bff_row_stats signatures are 30-bit keys */
 
 /* Device twin of bff_host_component_csr for at most `cap` <= BFF_GROUP_CAP kept groups.  comp[i] = smallest row index
@@ -388,6 +397,14 @@ int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n_rows, cons
  * [k_cap][k_cap]. */
 int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *inter, const int32_t *size,
                              const uint64_t *keep, int32_t *before, int32_t *after, const int32_t *k_dev, void *stream);
+/* out[r] bit perm[s] = in[r] bit s, set bits only (undoes the spatial point sort by scatter: aggregated rows are
+ * sparse); out must be zero; rows >= *k_dev (when given) are skipped. */
+int bff_scatter_bits(const uint64_t *rows_in, int32_t n_rows, int64_t nw_in, const int32_t *perm, int64_t n,
+                     int64_t nw_out, uint64_t *rows_out, const int32_t *k_dev, void *stream);
+/* bff_cross_popcount when only the first *k_dev rows of b's leading `lead` rows (and of a, with limit_a) are
+ * non-zero: tiles inside the zero part are skipped; inter is zeroed first. */
+int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint64_t *b, int32_t nb, int64_t nw, int32_t *inter,
+                           const int32_t *k_dev, int32_t limit_a, int32_t lead, void *stream);
 /* bff_clear_flagged_chunks unless *veto != 0 (device flag). */
 int bff_clear_flagged_chunks_unless(uint64_t *rows, int32_t n_rows, int64_t nw, const uint64_t *chunk_mask,
                                     const int32_t *veto, void *stream);
@@ -404,7 +421,8 @@ typedef struct bff_scene {
     const int32_t *run_start, *run_end, *mask_run_offs, *view_mask_offs;                     /* 2-D RLE run tables */
     const void *conf;               /* [n_rows] float16 / float32 */
     const int32_t *label_id;        /* [n_rows] */
-    const int32_t *unsort;          /* [n_points] or NULL */
+    const int32_t *unsort;          /* [n_points] position of original point o in the sorted cloud, or NULL */
+    const int32_t *perm;            /* [n_points] original index of sorted position s (inverse of unsort), or NULL */
     const int32_t *s1_run_start, *s1_run_end, *s1_row_run_offs;     /* stage-1 run tables or NULL */
     int32_t height, width, n_frames, n_mviews, word_bits, n_rows, conf_f16, n_label_ids, s1_rows, pad_;
 } bff_scene;
@@ -437,12 +455,12 @@ typedef struct bff_scene_workspace {
 #define BFF_HDR_K 0                 /* info[4] of bff_group_components: K, flags, largest group, slices */
 #define BFF_HDR_NUNIQUE 4           /* distinct filter values (0: the reference would raise IndexError) */
 #define BFF_HDR_THR 5               /* float32 threshold */
-#define BFF_HDR_SIZES 16            /* [64] members per group */
-#define BFF_HDR_FIRST 80            /* [64] smallest member of the group */
-#define BFF_HDR_BEFORE 144          /* [64] popcount before overlap resolution (P:592) */
-#define BFF_HDR_AFTER 208           /* [64] popcount after overlaps + point filter (P:596) */
-#define BFF_HDR_CONF 272            /* [64] confidence means, in the confidence dtype, packed */
-#define BFF_HDR_CROSS 336           /* [s1_rows][64 + s1_rows] stage-1 x (stage-2 groups | stage-1) intersections */
+#define BFF_HDR_SIZES 16                              /* [cap] members per group */
+#define BFF_HDR_FIRST (16 + BFF_GROUP_CAP)            /* [cap] smallest member of the group */
+#define BFF_HDR_BEFORE (16 + 2 * BFF_GROUP_CAP)       /* [cap] popcount before overlap resolution (P:592) */
+#define BFF_HDR_AFTER (16 + 3 * BFF_GROUP_CAP)        /* [cap] popcount after overlaps + point filter (P:596) */
+#define BFF_HDR_CONF (16 + 4 * BFF_GROUP_CAP)         /* [cap] confidence means, in the confidence dtype, packed */
+#define BFF_HDR_CROSS (16 + 5 * BFF_GROUP_CAP)        /* [s1_rows][cap + s1_rows] stage-1 x (stage-2 groups | stage-1) */
 int32_t bff_scene_header_words(int32_t s1_rows);
 int32_t bff_scene_struct_bytes(int32_t which);     /* 0 bff_scene, 1 bff_scene_params, 2 bff_scene_workspace */
 

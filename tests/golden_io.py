@@ -126,3 +126,25 @@ def dumps_groups(groups) -> np.ndarray:
 
 def loads_groups(arr):
     return json.loads(str(arr))
+
+
+def eval_case(z, name):
+    """One case of tests/golden/eval_assign.npz -> (preds, gts_sem, gts_ins, use_label, expected flat arrays)."""
+    sem, ins = z[f"{name}.sem"], z[f"{name}.ins"]
+    n = sem.shape[0]
+    masks = np.unpackbits(z[f"{name}.pred_masks"], axis=-1, count=n, bitorder="little")
+    preds = [{"scan_id": str(s), "label_id": float(l), "conf": float(c), "pred_mask": (m * v).astype(np.uint8)}
+             for s, l, c, m, v in zip(z[f"{name}.pred_scan"], z[f"{name}.pred_label"], z[f"{name}.pred_conf"], masks,
+                                      z[f"{name}.pred_values"])]
+    exp = {k.split(".out.")[1]: z[k] for k in z.files if k.startswith(f"{name}.out.")}
+    return preds, sem, ins, bool(z[f"{name}.use_label"]), exp
+
+
+def same_assignment(got: dict, exp: dict):
+    for k, v in exp.items():
+        if v.dtype.kind == "f":
+            assert np.array_equal(got[k], v), k                 # ious are float(int) / int: identical everywhere
+        elif v.dtype.kind == "U":
+            assert list(got[k]) == list(v), k
+        else:
+            assert np.array_equal(got[k], v), k

@@ -394,9 +394,10 @@ def test_resolve_overlaps_golden(lib):
         assert np.array_equal(unpack(rows, 3000), exp)
 
 
-@pytest.mark.parametrize("k,n", [(1, 100), (2, 64), (17, 5000), (64, 777), (70, 3000)])
+@pytest.mark.parametrize("k,n", [(1, 100), (2, 64), (17, 5000), (64, 777), (70, 3000), (200, 4100), (256, 500), (300, 900)])
 def test_resolve_overlaps_filtered_equals_separate_steps(lib, k, n):
-    """Fused pass (k <= 64) and the fallback (k = 70) == popcount, resolve_overlaps, and_rows, popcount."""
+    """Fused pass (k <= 256: pair masks of up to four 64-bit words) and the fallback (k = 300) == popcount,
+    resolve_overlaps, and_rows, popcount."""
     rng = np.random.default_rng(k)
     d = random_rows(rng, k, n, 0.08)
     keep = pack_np(rng.random((1, n)) < 0.7)[0]
@@ -730,3 +731,66 @@ def test_frustum_culling_is_exact(lib):
     # behind-the-camera visibility exists in this data (otherwise the back cone would be untested)
     cam0 = (inv[0] @ np.concatenate([xyz, np.ones((n, 1))], 1).T).T
     assert ((cam0[:, 2] < 0) & (np.abs(cam0[:, 2] - 0.03) < 0.08)).sum() > 10
+
+
+@pytest.mark.parametrize("name", ["labelled_a", "labelled_b", "agnostic", "no_preds"])
+def test_evaluation_assignment_golden(lib, name):
+    """evaluation.assign_instances_for_scan (bit rows + one popcount Gram on the device) reproduces the nested dicts
+    of the reference's ScanNetEval.assign_instances_for_scan (scannetv2_inst_eval.py:265-365) on the golden cases:
+    labels the evaluator does not know, predictions below the minimum region size, empty masks, void classes,
+    ignored instance ids, class-agnostic mode, no predictions at all; also from pre-packed device rows."""
+    from beyond_fixed_forms_amd.evaluation import assign_instances_for_scan
+    from oracle.eval_ref import flatten_assignment
+    z = Z("eval_assign.npz")
+    labels = [str(s) for s in z["class_labels"]]
+    preds, sem, ins, use_label, exp = gio.eval_case(z, name)
+    ev_labels = labels if use_label else ["class_agnostic"]
+    gt2pred, pred2gt = assign_instances_for_scan(preds, sem, ins, labels, use_label=use_label, device=DEV)
+    gio.same_assignment(flatten_assignment(gt2pred, pred2gt, ev_labels), exp)
+    if preds:
+        rows = pack_np(np.stack([p["pred_mask"] != 0 for p in preds]))
+        slim = [{k: v for k, v in p.items() if k != "pred_mask"} for p in preds]
+        gt2pred, pred2gt = assign_instances_for_scan(slim, sem, ins, labels, use_label=use_label, device=DEV, pred_rows=rows)
+        gio.same_assignment(flatten_assignment(gt2pred, pred2gt, ev_labels), exp)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f16"])
+def test_box_filter_golden(lib, tag):
+    """The arithmetic around the CLIP box filter (segmentation_2d.py:324-337, 388-396) against what the reference's own
+    functions produced with injected embeddings (tests/golden/box_filter.npz): per-class means of normalised
+    description encodings, F.normalize(box_emb) @ text_mean.T on the matrix cores, the `>= 0.2` decisions.
+    Tolerance: 1e-4 (north_star) for float32 encodings; the reference's fp16 path rounds every tensor op to fp16,
+    so its values sit up to a few fp16 ulps (2^-11 each) from the exact ones the device approximates."""
+    from beyond_fixed_forms_amd import boxfilter
+    z = Z("box_filter.npz")
+    dt = torch.float32 if tag == "f32" else torch.float16
+    counts = z[f"{tag}.desc_counts"]
+    desc = torch.from_numpy(z[f"{tag}.desc"]).to(dt)
+    enc = [desc[a:b] for a, b in zip(np.cumsum([0] + list(counts[:-1])), np.cumsum(counts))]
+    means = boxfilter.average_description_embeddings(enc, DEV)
+    assert means.dtype == dt and tuple(means.shape) == tuple(z[f"{tag}.desc_means"].shape)
+    tol = 1e-4 if tag == "f32" else 3 * 2.0 ** -11
+    assert np.abs(means.float().cpu().numpy() - z[f"{tag}.desc_means"]).max() <= tol
+    # the filter, fed with the reference's own text mean (so the comparison isolates the product)
+    emb = torch.from_numpy(z[f"{tag}.box_emb"]).to(dt)
+    text = torch.from_numpy(z[f"{tag}.desc_means"][0:1]).to(dt)
+    boxes = torch.from_numpy(z[f"{tag}.boxes"])
+    phrases = [f"p{i}" for i in range(emb.shape[0])]
+    b_f, logits, phr = boxfilter.bbox_filter(boxes, phrases, emb.to(DEV), text.to(DEV), clip_threshold=0.2)
+    sims = boxfilter.box_similarities(emb.to(DEV), text.to(DEV)).cpu().numpy()[:, 0]
+    exact = (torch.nn.functional.normalize(emb.double()) @ text.double().T).numpy()[:, 0]
+    assert np.abs(sims - exact).max() <= 1e-4                                     # vs float64 on the same inputs
+    kept_ref = z[f"{tag}.kept"]
+    assert np.abs(sims[kept_ref] - z[f"{tag}.logits"]).max() <= tol
+    clear = np.abs(exact - 0.2) > tol                                             # decisions away from the threshold
+    got_kept = np.array([int(p[1:]) for p in phr])
+    assert np.array_equal(got_kept[clear[got_kept]], kept_ref[clear[kept_ref]])
+    assert torch.equal(b_f, boxes[torch.from_numpy(got_kept)]) and logits.shape == (len(got_kept), 1)
+    # batched form: every box of many frames against a 200-label bank in one launch (BASELINE config 5 shape)
+    gen = torch.Generator().manual_seed(9)
+    many = torch.randn(5000, 768, generator=gen).half()
+    bank = torch.nn.functional.normalize(torch.randn(200, 768, generator=gen)).half()
+    big = boxfilter.box_similarities(many.to(DEV), bank.to(DEV)).cpu().double()
+    ref = torch.nn.functional.normalize(many.double()) @ bank.double().T
+    assert (big - ref).abs().max().item() <= 1e-4
+    assert boxfilter.bbox_filter(boxes[:0], [], emb[:0], text, 0.2)[1:] == ([], [])                # SEG:354-355

@@ -196,11 +196,13 @@ def test_refinement_merge_branches(api, variant):
 
 
 def test_row_arena_recycling(api):
-    """The instance rows of the non-debug path are a view of a per-stream zero arena that the back half clears
-    sparsely.  Several scenes of different shapes through the same arena, a front half whose back half never runs
-    (arena left dirty: must be dropped, not reused) and the plain-tensor debug path all give the same results."""
+    """The instance rows are a zero arena that is cleared sparsely once their last reader is done: the workspace of
+    bff_scene_project (one per stream; the clear is part of the call) and _lib.RowArena for the step-by-step path.
+    Several scenes of different shapes through the same arenas, a front whose results are never collected (arena
+    possibly dirty: it must be zeroed again, never handed out dirty) and the plain-tensor debug path all give the same
+    results, and the arenas are all zero whenever nothing is in flight."""
     projection, _ = api
-    from beyond_fixed_forms_amd import _lib
+    from beyond_fixed_forms_amd import _lib, pipeline
     from beyond_fixed_forms_amd.scene import prepare_scene
     from beyond_fixed_forms_amd.synthetic import make_scene
     scenes = [make_scene("tiny", seed=31), make_scene("tiny", seed=32, n_points=4001, n_masks=40), make_scene("c1", seed=33)]
@@ -209,16 +211,24 @@ def test_row_arena_recycling(api):
         cfg = cfg_for(sc)
         ref.append(projection.run_projection(prepare_scene(sc, cfg, device=DEV), cfg, debug_out=True))    # own tensors
     arena = _lib.RowArena.for_current_stream(torch.device(DEV))
-    for rnd in range(2):
-        for sc, exp in zip(scenes, ref):
-            cfg = cfg_for(sc)
-            ds = prepare_scene(sc, cfg, device=DEV)
-            if rnd == 1 and sc is scenes[1]:
-                projection.projection_front(ds, cfg)                 # abandoned: its rows stay dirty in the arena
-                assert arena.busy
-            got = projection.run_projection(ds, cfg)
-            assert not arena.busy and (arena.buf is None or int(arena.buf.count_nonzero()) == 0)
-            assert torch.equal(got.rows, exp.rows) and torch.equal(got.conf, exp.conf) and got.groups == exp.groups
+    for fast in (True, False):
+        for rnd in range(2):
+            for sc, exp in zip(scenes, ref):
+                cfg = cfg_for(sc)
+                ds = prepare_scene(sc, cfg, device=DEV)
+                if rnd == 1 and sc is scenes[1]:
+                    projection.projection_front(ds, cfg, fast=fast)          # abandoned: its rows stay dirty
+                    if not fast:
+                        assert arena.busy
+                got = projection.projection_back(projection.projection_front(ds, cfg, fast=fast))
+                assert got.debug.get("path", "step") == ("fast" if fast else "step")
+                if fast:
+                    ws = pipeline.SceneWorkspace.for_current_stream(torch.device(DEV))
+                    torch.cuda.synchronize()
+                    assert not ws.in_flight and not ws.rows_dirty and int(ws.t["rows"].count_nonzero()) == 0
+                else:
+                    assert not arena.busy and (arena.buf is None or int(arena.buf.count_nonzero()) == 0)
+                assert torch.equal(got.rows, exp.rows) and torch.equal(got.conf, exp.conf) and got.groups == exp.groups
 
 
 def test_raw_depth_path_equals_float_depth_path(api):
@@ -426,18 +436,21 @@ def test_similarity_set_near_ties(api, enc_dtype):
     assert dropped > 0                                                    # the threshold did bite
 
 
-@pytest.mark.parametrize("case", ["more_than_64_groups", "min_members_0", "many_stage2"])
+@pytest.mark.parametrize("case", ["more_groups_than_the_device_forms", "hundred_groups", "min_members_0", "many_stage2"])
 def test_fast_path_and_its_fallbacks(api, case):
     """bff_scene_project (one native call per scene, groups formed on the device) against the oracle and against the
-    step-by-step path: (a) a scene whose merge graph has more than 64 kept groups -- the device tables are
-    incomplete, the host continues from the components (general path); (b) min_aggragated_masks = 0, where the
-    reference's empty components survive the filter (general path too); (c) a scene with many surviving stage-2
-    instances on the fast path.  Stage-2 and final results are bit-identical in all cases."""
+    step-by-step path: (a) a scene whose merge graph has more kept groups than BFF_GROUP_CAP = 256 -- the device tables
+    are incomplete, the host continues from the components (general path); (a') ~90 groups, handled on the device
+    (pair masks of several words in the fused overlap pass); (b) min_aggragated_masks = 0, where the reference's empty
+    components survive the filter (general path too); (c) a scene with many surviving stage-2 instances on the fast
+    path.  Stage-2 and final results are bit-identical in all cases."""
     projection, refinement = api
     from beyond_fixed_forms_amd.scene import prepare_scene
     from beyond_fixed_forms_amd.synthetic import make_scene, make_text_bank
     over = {}
-    if case == "more_than_64_groups":
+    if case == "more_groups_than_the_device_forms":
+        scene = make_scene("tiny", seed=30, n_labels=50, n_masks=64, n_views=24, cut_masks=False)
+    elif case == "hundred_groups":
         scene = make_scene("tiny", seed=30, n_labels=12, n_masks=64, n_views=6, cut_masks=False)
     elif case == "min_members_0":
         scene = make_scene("tiny", seed=31)
@@ -455,10 +468,12 @@ def test_fast_path_and_its_fallbacks(api, case):
     slow = projection.run_projection(ds, cfg, debug_out=True)                  # step by step
     if case == "many_stage2":
         assert res.debug["path"] == "fast" and exp["ins"].shape[0] >= 5
+    elif case == "hundred_groups":
+        assert res.debug["path"] == "fast" and 64 < len(dbg["groups"]) <= 256
     else:
         assert res.debug["path"].startswith("general")
-        if case == "more_than_64_groups":
-            assert len(dbg["groups"]) > 64
+        if case == "more_groups_than_the_device_forms":
+            assert len(dbg["groups"]) > 256
     assert list(res.groups) == list(slow.groups) == dbg["groups"]
     same(res.to_dict(), exp)
     same(slow.to_dict(), exp)

@@ -162,3 +162,15 @@ def test_whole_scene(name):
     bank, index = make_text_bank(int(z["bank_dim"]), seed=int(z["bank_seed"]))
     fin = rref.refine_class_ref([(scene.scene_id, scene.stage1, res)], cfg, "table", bank_encoder(bank.float(), index))
     _check_result(fin[scene.scene_id], z, "final", n)
+
+
+@pytest.mark.parametrize("name", ["labelled_a", "labelled_b", "agnostic", "no_preds"])
+def test_evaluation_assignment_restatement(name):
+    """oracle/eval_ref.py against what the reference's ScanNetEval.assign_instances_for_scan produced
+    (tests/golden/eval_assign.npz, written by oracle/make_golden_eval.py from the imported method)."""
+    from oracle.eval_ref import assign_instances_ref, flatten_assignment
+    z = Z("eval_assign.npz")
+    labels = [str(s) for s in z["class_labels"]]
+    preds, sem, ins, use_label, exp = gio.eval_case(z, name)
+    gt2pred, pred2gt = assign_instances_ref(preds, sem, ins, labels, use_label=use_label)
+    gio.same_assignment(flatten_assignment(gt2pred, pred2gt, labels if use_label else ["class_agnostic"]), exp)
