@@ -33,7 +33,7 @@ SIGNATURES = {
     "bff_permute_bits": [_P, _I, _L, _P, _L, _L, _P, _P],
     "bff_components_round": [_P, _I, _P, _P, _P, _P],
     "bff_or_reduce_groups": [_P, _L, _P, _P, _I, _I, _P, _P, _I, _P, _P],
-    "bff_resolve_overlaps": [_P, _I, _L, _P, _P, _P, _P, _P, _P],
+    "bff_resolve_overlaps": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P],
     "bff_group_conf_mean": [_P, _I, _P, _P, _I, _P, _P],
     "bff_apply_row_ops": [_P, _L, _P, _I, _P],
     "bff_overlap_ops": [_P, _P, _I, _P, _P],
@@ -52,11 +52,12 @@ SIGNATURES = {
     "bff_cosine_rows": [_P, _I, _P, _I, _I, _I, _P, _P],
     "bff_normalized_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
     "bff_description_means": [_P, _P, _I, _I, _I, _P, _P],
-    "bff_group_components": [_P, _P, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "bff_group_components": [_P, _P, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "bff_or_reduce_grouped": [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
-    "bff_resolve_overlaps_dev": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P],
+    "bff_resolve_overlaps_dev": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "bff_clear_flagged_chunks_unless": [_P, _I, _L, _P, _P, _P],
     "bff_scene_project": [_P, _P, _P, _P],
+    "bff_diag_gather": [_P, _L, _L, _P, _P],
     "bff_scatter_bits": [_P, _I, _L, _P, _L, _L, _P, _P, _P],
     "bff_cross_popcount_dev": [_P, _I, _P, _I, _L, _P, _P, _I, _I, _P],
     "bff_cloud_layout": [_P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -68,7 +69,7 @@ PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, [
          "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
          "bff_point_tile_size": (c_int32, []), "bff_merge_scratch_words": (c_int64, [c_int32]),
          "bff_profile_next_merge": (c_int32, [_P, _P]), "bff_group_slice_cap": (c_int32, [c_int32, c_int32]),
-         "bff_scene_header_words": (c_int32, [c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
+         "bff_resolve_overlaps_scratch_words": (c_int64, []), "bff_scene_header_words": (c_int32, [c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
          "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
          "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}
@@ -385,8 +386,9 @@ def resolve_overlaps_filtered(rows, sizes, keep):
     if k <= load().bff_resolve_overlaps_max_rows():
         before = torch.empty(k, dtype=i32, device=rows.device)
         after = torch.empty(k, dtype=i32, device=rows.device)
+        pm = torch.empty(int(load().bff_resolve_overlaps_scratch_words()), dtype=i64, device=rows.device)
         call("bff_resolve_overlaps", _ptr(rows, i64), k, rows.shape[1], _ptr(inter, i32), _ptr(sizes, i32),
-             _ptr(keep, i64), _ptr(before), _ptr(after))
+             _ptr(keep, i64), _ptr(before), _ptr(after), _ptr(pm))
         return before, after
     before = inter.diagonal().contiguous()
     if k >= 2:

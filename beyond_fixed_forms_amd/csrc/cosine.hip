@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_strip_kernel(const _Float
             atomicAdd(&s_nb[row], q);
         }
         __syncthreads();
-#pragma unroll 4
         for (int k0 = 0; k0 < kn; k0 += 32) {
             const half8 fa = ra ? *reinterpret_cast<const half8 *>(pa + kc + k0) : zero;
 #pragma unroll

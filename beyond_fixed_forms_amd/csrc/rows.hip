@@ -7,6 +7,8 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "common.h"
 
 static thread_local hipEvent_t g_merge_start = nullptr, g_merge_stop = nullptr;   // bff_profile_next_merge
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
         const int kd = *k_dev;
         if (lim_a && (int)blockIdx.y * kT >= kd) return;
         if ((int)blockIdx.x * kT >= kd && (int)(blockIdx.x + 1) * kT <= hole_hi) return;
+        if (lim_a == 2 && blockIdx.y > blockIdx.x) return;        // a == b and only entries j >= i are read
     }
     // blockIdx.z owns the word range [z*k_split, (z+1)*k_split): small row counts still fill the chip.
     // Partial counts are combined with integer atomics (exact, order independent) into a zeroed matrix.
@@ -1171,7 +1174,7 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restr
 {
     __shared__ int wsum[16];
     __shared__ int s_base, s_void, s_max;
-    __shared__ int s_off[kFuseMax + 1], s_soff[kFuseMax + 1];
+    __shared__ int s_off[kFuseMax + 1], s_soff[kFuseMax + 1], s_sz[kFuseMax];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { s_base = 0; s_void = 0; s_max = 0; }
     __syncthreads();
@@ -1193,7 +1196,7 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restr
         int g = s_base + __popcll(bal & ((1ull << lane) - 1));
         for (int q = 0; q < wave; ++q) g += wsum[q];
         if (valid) {
-            if (g < cap) { sizes[g] = sz; first[g] = c; }
+            if (g < cap) { sizes[g] = sz; first[g] = c; s_sz[g] = sz; }
             atomicMax(&s_max, sz);
         }
         __syncthreads();
@@ -1203,7 +1206,7 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restr
     const int k_all = s_base, k = min(k_all, cap);
     if (tid == 0) {
         int o = 0, so = 0;
-        for (int g = 0; g < k; ++g) { s_off[g] = o; s_soff[g] = so; o += sizes[g]; so += (sizes[g] + kOrSplit - 1) / kOrSplit; }
+        for (int g = 0; g < k; ++g) { s_off[g] = o; s_soff[g] = so; o += s_sz[g]; so += (s_sz[g] + kOrSplit - 1) / kOrSplit; }
         s_off[k] = o; s_soff[k] = so;
         info[0] = k_all;
         info[1] = (k_all > cap ? 1 : 0) | ((min_members <= 0 && s_void > 0) ? 2 : 0);
@@ -1361,11 +1364,38 @@ __global__ void apply_row_ops_kernel(uint64_t *__restrict__ rows, int64_t nw, co
 // ordered pair loop on its own column (the pair flags come from the intersections BEFORE any edit, P:289-292),
 // ANDs with `keep`, writes the column back and the wave adds the columns' popcounts to after[].
 
+// Pair flags of solve_overlapping (P:289-292) from the intersections BEFORE any edit: pmask[i] = bit set over the
+// rows j > i that overlap row i (kFuseMax / 64 words per row), before[i] = |row i| (P:592).  One wave per row.
+constexpr int kMW = kFuseMax / 64;
+
+__global__ __launch_bounds__(256) void overlap_masks_kernel(const int32_t *__restrict__ inter, int stride, int k,
+                                                             const int32_t *__restrict__ k_dev,
+                                                             unsigned long long *__restrict__ pmask,
+                                                             int32_t *__restrict__ before)
+{
+    if (k_dev) {
+        const int kd = *k_dev;
+        if (kd <= 0 || kd > k) return;
+        k = kd;
+    }
+    const int lane = lane_id();
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= k) return;
+#pragma unroll
+    for (int q = 0; q < kMW; ++q) {
+        const int j = 64 * q + lane;
+        const int v = j < k ? inter[(int64_t)i * stride + j] : 0;
+        const unsigned long long m = __ballot(v > 0 && j > i);
+        if (lane == 0) pmask[(int64_t)i * kMW + q] = m;
+        if (j == i) before[i] = v;
+    }
+}
+
 __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restrict__ rows, int64_t nw, int k,
-                                                              const int32_t *__restrict__ inter, int stride,
+                                                              const unsigned long long *__restrict__ pmask,
                                                               const int32_t *__restrict__ size,
                                                               const uint64_t *__restrict__ keep,
-                                                              int32_t *__restrict__ before, int32_t *__restrict__ after,
+                                                              int32_t *__restrict__ after,
                                                               const int32_t *__restrict__ k_dev)
 {
     // k_dev != NULL: the row count lives on the device (groups formed there); k is then the capacity the launch
@@ -1376,31 +1406,22 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
         k = kd;
     }
     constexpr int kPitch = kWave + 1;                        // column- and row-wise LDS accesses both conflict-free
-    constexpr int kMW = kFuseMax / 64;                       // 64-bit words of a row's pair mask
-    __shared__ unsigned long long s_mask[kFuseMax][kMW];     // row i -> rows j > i that overlap it
+    __shared__ unsigned long long s_mask[kFuseMax * kMW];    // row i -> rows j > i that overlap it
     __shared__ int s_size[kFuseMax];
     extern __shared__ uint64_t s_dyn[];
     uint64_t *s_col = s_dyn;                                 // [k][kPitch]
     const int t = threadIdx.x;
     const int64_t w = (int64_t)blockIdx.x * kWave + t;
     const int kw = (k + 63) / 64;
-    // independent loads, several in flight: this thread's word of every row, then the pair flags (from the
-    // intersections BEFORE any edit, P:289-292) as ballots straight out of global memory
+    // independent loads, several in flight: the pair masks, the sizes, then this thread's word of every row
+    for (int q = t; q < k * kMW; q += kWave) s_mask[q] = pmask[q];
+    for (int r = t; r < k; r += kWave) s_size[r] = size[r];
 #pragma unroll 8
     for (int r = 0; r < k; ++r) s_col[r * kPitch + t] = w < nw ? rows[(int64_t)r * nw + w] : 0;
-    for (int r = t; r < k; r += kWave) s_size[r] = size[r];
-    for (int i = 0; i < k; ++i)
-        for (int q = 0; q < kw; ++q) {
-            const int j = 64 * q + t;
-            const int v = j < k ? inter[(int64_t)i * stride + j] : 0;
-            const unsigned long long m = __ballot(v > 0 && j > i);
-            if (t == 0) s_mask[i][q] = m;
-            if (j == i && blockIdx.x == 0) before[i] = v;     // popcount of the row before any edit (P:592)
-        }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // single wave: its LDS ops complete in order
     for (int i = 0; i < k; ++i)
         for (int q = 0; q < kw; ++q) {
-            unsigned long long m = s_mask[i][q];              // wave-uniform
+            unsigned long long m = s_mask[i * kMW + q];       // wave-uniform
             while (m) {
                 const int j = 64 * q + __ffsll(m) - 1;
                 m &= m - 1;
@@ -1756,10 +1777,16 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
         uint64_t *pass2 = reinterpret_cast<uint64_t *>((p2 + 7) & ~(uintptr_t)7);
         tile_masks_kernel<<<nt, 256, 0, st>>>(chunk_mask, order, n_order, mw, tile_mask, hist, hist_sorted, (int)n_pos, area,
                                              tile_hmax, tile_amin, label_id, row_sorted, area_sorted, label_sorted);
-        constexpr int kStrides = 4;                                    // 1, 2, 3, 5 (more strides measured no faster)
-        dim3 sgrid((unsigned)ceil_div(n_order, 4), kStrides);
-        uf_skeleton_kernel<<<sgrid, 256, 0, st>>>(rows, n_order, nw, order, chunk_mask, mw, area, label_id, iou_thres,
-                                                  parent, kStrides);
+        static const int kStrides = [] {                               // 1, 2, 3, 5 (more strides measured no faster)
+            const char *e = getenv("BFF_SKELETON_STRIDES");            // experiment knob: 0 switches the pre-pass off
+            const int v = e ? atoi(e) : 4;
+            return v < 0 ? 0 : (v > 8 ? 8 : v);
+        }();
+        if (kStrides > 0) {
+            dim3 sgrid((unsigned)ceil_div(n_order, 4), (unsigned)kStrides);
+            uf_skeleton_kernel<<<sgrid, 256, 0, st>>>(rows, n_order, nw, order, chunk_mask, mw, area, label_id, iou_thres,
+                                                      parent, kStrides);
+        }
         hipError_t e = hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), st);
         if (e != hipSuccess) return fail((int)e, "bff_merge_components: memset: %s", hipGetErrorString(e));
         tile_pair_filter_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(tile_hmax, tile_amin, nt, (int)total,
@@ -1852,33 +1879,42 @@ extern "C" int bff_overlap_ops(const int32_t *inter, const int32_t *size, int32_
     return launched("bff_overlap_ops");
 }
 
+// pair masks live in a small device scratch owned by the library (kFuseMax x 4 words per stream slot is tiny, but a
+// global buffer would race between streams): the callers pass one, see bff_hip.h
+extern "C" int64_t bff_resolve_overlaps_scratch_words(void) { return (int64_t)kFuseMax * kMW; }
+
 extern "C" int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const int32_t *inter, const int32_t *size,
-                                    const uint64_t *keep, int32_t *before, int32_t *after, void *stream)
+                                    const uint64_t *keep, int32_t *before, int32_t *after, uint64_t *pair_masks,
+                                    void *stream)
 {
     BFF_REQUIRE(k >= 0 && nw >= 0, "bff_resolve_overlaps: bad sizes");
     BFF_LIMIT(k <= kFuseMax, "bff_resolve_overlaps: more than %d rows (use bff_overlap_ops + bff_apply_row_ops)", kFuseMax);
     if (k == 0) return BFF_OK;
-    BFF_REQUIRE(rows && inter && size && before && after, "bff_resolve_overlaps: null pointer");
+    BFF_REQUIRE(rows && inter && size && before && after && pair_masks, "bff_resolve_overlaps: null pointer");
     hipError_t e = hipMemsetAsync(after, 0, sizeof(int32_t) * (size_t)k, as_stream(stream));
     if (e != hipSuccess) return fail((int)e, "bff_resolve_overlaps: memset: %s", hipGetErrorString(e));
+    overlap_masks_kernel<<<(unsigned)ceil_div(k, 4), 256, 0, as_stream(stream)>>>(inter, k, k, nullptr,
+                                                                                (unsigned long long *)pair_masks, before);
     BFF_TRY_LDS(sizeof(uint64_t) * (size_t)k * (kWave + 1), "bff_resolve_overlaps");
     resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave, sizeof(uint64_t) * (size_t)k * (kWave + 1),
-                              as_stream(stream)>>>(rows, nw, k, inter, k, size, keep, before, after, nullptr);
+                              as_stream(stream)>>>(rows, nw, k, (const unsigned long long *)pair_masks, size, keep, after, nullptr);
     return launched("bff_resolve_overlaps");
 }
 
 extern "C" int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *inter,
                                         const int32_t *size, const uint64_t *keep, int32_t *before, int32_t *after,
-                                        const int32_t *k_dev, void *stream)
+                                        uint64_t *pair_masks, const int32_t *k_dev, void *stream)
 {
     BFF_REQUIRE(k_cap > 0 && nw >= 0, "bff_resolve_overlaps_dev: bad sizes");
     BFF_LIMIT(k_cap <= kFuseMax, "bff_resolve_overlaps_dev: capacity beyond %d rows", kFuseMax);
-    BFF_REQUIRE(rows && inter && size && before && after && k_dev, "bff_resolve_overlaps_dev: null pointer");
+    BFF_REQUIRE(rows && inter && size && before && after && k_dev && pair_masks, "bff_resolve_overlaps_dev: null pointer");
     hipError_t e = hipMemsetAsync(after, 0, sizeof(int32_t) * (size_t)k_cap, as_stream(stream));
     if (e != hipSuccess) return fail((int)e, "bff_resolve_overlaps_dev: memset: %s", hipGetErrorString(e));
+    overlap_masks_kernel<<<(unsigned)ceil_div(k_cap, 4), 256, 0, as_stream(stream)>>>(inter, k_cap, k_cap, k_dev,
+                                                                                    (unsigned long long *)pair_masks, before);
     BFF_TRY_LDS(sizeof(uint64_t) * (size_t)k_cap * (kWave + 1), "bff_resolve_overlaps_dev");
     resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave, sizeof(uint64_t) * (size_t)k_cap * (kWave + 1),
-                              as_stream(stream)>>>(rows, nw, k_cap, inter, k_cap, size, keep, before, after, k_dev);
+                              as_stream(stream)>>>(rows, nw, k_cap, (const unsigned long long *)pair_masks, size, keep, after, k_dev);
     return launched("bff_resolve_overlaps_dev");
 }
 
@@ -1982,7 +2018,8 @@ extern "C" int bff_ids_to_rows(const int64_t *ids, int64_t n_points, const int64
 extern "C" int32_t bff_group_slice_cap(int32_t n_rows, int32_t cap) { return n_rows / kOrSplit + cap + 1; }
 
 extern "C" int bff_group_components(const int32_t *comp, const int32_t *area, int32_t n_rows, float iou_thres,
-                                    int32_t min_members, int32_t cap, int32_t *count, int32_t *info, int32_t *sizes,
+                                    int32_t min_members, int32_t cap, int32_t *count, int32_t count_is_zero,
+                                    int32_t *info, int32_t *sizes,
                                     int32_t *first, int32_t *offs, int32_t *members, int32_t *slices, void *stream)
 {
     BFF_REQUIRE(n_rows >= 0 && cap > 0, "bff_group_components: bad sizes");
@@ -1991,8 +2028,10 @@ extern "C" int bff_group_components(const int32_t *comp, const int32_t *area, in
                 "bff_group_components: null pointer");
     hipStream_t st = as_stream(stream);
     if (n_rows > 0) {
-        hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t) * (size_t)n_rows, st);
-        if (e != hipSuccess) return fail((int)e, "bff_group_components: memset: %s", hipGetErrorString(e));
+        if (!count_is_zero) {
+            hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t) * (size_t)n_rows, st);
+            if (e != hipSuccess) return fail((int)e, "bff_group_components: memset: %s", hipGetErrorString(e));
+        }
         group_count_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(comp, n_rows, count);
     }
     group_scan_kernel<<<1, 1024, 0, st>>>(comp, count, area, n_rows, iou_thres, min_members, cap, info, sizes, first, offs,

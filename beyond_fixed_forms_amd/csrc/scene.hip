@@ -61,11 +61,13 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     // a1: 2-D RLE -> mask words (+ segment bitmap)
     BFF_TRY(bff_rle_to_maskbits(sc->run_start, sc->run_end, sc->mask_run_offs, sc->view_mask_offs, sc->n_mviews, hw,
                                 sc->word_bits, ws->maskbits, ws->segmap, stream));
-    // a2-a8 (+a15): the fused sweep.  ws->rows is all zero on entry (and again on exit, see below)
-    BFF_ZERO(ws->masked, sizeof(int32_t) * (size_t)n);
+    // a2-a8 (+a15): the fused sweep.  ws->rows is all zero on entry (and again on exit, see below); the counters,
+    // the group counters and the chunk flags are one block, cleared by one fill
     const bool ratio = pr->filter_mode == 2;
-    if (ratio) BFF_ZERO(ws->viewed, sizeof(int32_t) * (size_t)n);
-    BFF_ZERO(ws->chunk_mask, sizeof(uint64_t) * (size_t)n_rows * mw);
+    BFF_REQUIRE(ws->zero_bytes >= sizeof(int32_t) * (size_t)(2 * n + n_rows) + sizeof(uint64_t) * (size_t)n_rows * mw &&
+                reinterpret_cast<char *>(ws->chunk_mask) + sizeof(uint64_t) * (size_t)n_rows * mw <=
+                reinterpret_cast<char *>(ws->masked) + ws->zero_bytes, "bff_scene_project: zero block too small");
+    BFF_ZERO(ws->masked, ws->zero_bytes);
     BFF_ZERO(hdr, sizeof(int32_t) * BFF_HDR_SIZES);
     BFF_TRY(bff_project_views(sc->xyz, n, sc->n_pad, sc->inv_pose, sc->cam_intr, sc->n_frames, sc->depth, sc->depth_index,
                               sc->height, sc->width, pr->depth_thresh, ws->maskbits, ws->segmap, sc->word_bits,
@@ -102,7 +104,7 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
                                  stream));
     // P:203-226 on the device: groups, OR of the members, sequential confidence means
     int32_t *info = hdr + BFF_HDR_K;
-    BFF_TRY(bff_group_components(ws->comp, ws->area, n_rows, pr->iou_thres, pr->min_members, cap, ws->count, info,
+    BFF_TRY(bff_group_components(ws->comp, ws->area, n_rows, pr->iou_thres, pr->min_members, cap, ws->count, 1, info,
                                  hdr + BFF_HDR_SIZES, hdr + BFF_HDR_FIRST, ws->goffs, ws->gmembers, ws->slices, stream));
     BFF_TRY(bff_or_reduce_grouped(ws->rows, nw, n_rows, info, cap, ws->goffs, ws->gmembers, ws->slices, ws->agg, sc->conf,
                                   sc->conf_f16, hdr + BFF_HDR_CONF, stream));
@@ -110,9 +112,9 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     // path (more groups than the device forms), which reads the rows again and clears them itself
     BFF_TRY(bff_clear_flagged_chunks_unless(ws->rows, n_rows, nw, ws->chunk_mask, info + 1, stream));
     // a16 + P:592-596: intersections before any edit, ordered overlap decisions, &= keep, both popcounts
-    BFF_TRY(bff_cross_popcount_dev(ws->agg, cap, ws->agg, cap, nw, ws->inter, info, 1, cap, stream));
+    BFF_TRY(bff_cross_popcount_dev(ws->agg, cap, ws->agg, cap, nw, ws->inter, info, 2, cap, stream));
     BFF_TRY(bff_resolve_overlaps_dev(ws->agg, cap, nw, ws->inter, hdr + BFF_HDR_SIZES, ws->keep, hdr + BFF_HDR_BEFORE,
-                                     hdr + BFF_HDR_AFTER, info, stream));
+                                     hdr + BFF_HDR_AFTER, ws->pair_masks, info, stream));
     // caller's point order (scatter of the set bits); the refinement's first device pass (R:186-217) rides along when
     // stage 1 is resident
     if (sc->perm) {

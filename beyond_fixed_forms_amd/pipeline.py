@@ -41,12 +41,13 @@ class ParamsStruct(ctypes.Structure):
 
 _WS_PTRS = ["maskbits", "segmap", "rows", "chunk_mask", "keep", "tile_mask", "agg", "both",
             "masked", "viewed", "sel_scratch", "area", "mean_word", "order", "parent", "comp", "count",
-            "gmembers", "goffs", "slices", "inter", "vals", "vals_sorted", "hist", "merge_scratch",
+            "gmembers", "goffs", "slices", "inter", "pair_masks", "vals", "vals_sorted", "hist", "merge_scratch",
             "sig", "sig_keys", "sig_sorted", "sort_temp"]
 
 
 class WorkspaceStruct(ctypes.Structure):
-    _fields_ = [(n, c_void_p) for n in _WS_PTRS] + [("sort_temp_bytes", c_size_t), ("hdr", c_void_p), ("hdr_host", c_void_p)]
+    _fields_ = [(n, c_void_p) for n in _WS_PTRS] + [("sort_temp_bytes", c_size_t), ("zero_bytes", c_size_t),
+                                                      ("hdr", c_void_p), ("hdr_host", c_void_p)]
 
 
 _checked = False
@@ -153,14 +154,25 @@ class SceneWorkspace:
         self._need("segmap", n_mviews * _lib.segmap_words(hw), i32)
         if self._need("rows", n_rows * nw, i64, zero=True):
             self.rows_dirty = False
-        self._need("chunk_mask", n_rows * mw, i64)
+        # masked | viewed | count | chunk_mask: one allocation, cleared by one fill per scene
+        zwords = 2 * n + n_rows + (-(2 * n + n_rows)) % 2                 # int32 words before the 8-byte aligned flags
+        zbytes = 4 * zwords + 8 * n_rows * mw
+        if self._need("zero_block", zbytes, torch.uint8):
+            pass
+        zb = self.t["zero_block"]
+        for name, off in (("masked", 0), ("viewed", 4 * n), ("count", 8 * n), ("chunk_mask", 4 * zwords)):
+            setattr(self.struct, name, c_void_p(zb.data_ptr() + off))
+        self.t["masked"] = zb[0:4 * n].view(i32)
+        self.t["viewed"] = zb[4 * n:8 * n].view(i32)
+        self.t["count"] = zb[8 * n:8 * n + 4 * n_rows].view(i32)
+        self.t["chunk_mask"] = zb[4 * zwords:4 * zwords + 8 * n_rows * mw].view(i64)
+        self.struct.zero_bytes = zbytes
         self._need("keep", nw, i64)
         self._need("tile_mask", nt * mw, i64)
         self._need("agg", GROUP_CAP * nw, i64)
-        for k in ("masked", "viewed"):
-            self._need(k, n, i32)
         self._need("sel_scratch", (n + 1023) // 1024, i32)
-        for k in ("area", "mean_word", "order", "parent", "comp", "count", "gmembers"):
+        self._need("pair_masks", int(lib.bff_resolve_overlaps_scratch_words()), i64)
+        for k in ("area", "mean_word", "order", "parent", "comp", "gmembers"):
             self._need(k, n_rows, i32)
         self._need("goffs", GROUP_CAP + 1, i32)
         self._need("slices", 3 * lib.bff_group_slice_cap(n_rows, GROUP_CAP), i32)

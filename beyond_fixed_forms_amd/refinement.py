@@ -140,18 +140,20 @@ def _stage1_rows(stage1, device):
     return rows, st.n_points, st.labels
 
 
-def _iou(inter: torch.Tensor, area_a: torch.Tensor, area_b: torch.Tensor) -> torch.Tensor:
-    """calculate_iou_between_stages R:69-90 from integer intersections: (m, n) float32."""
-    inter = inter.to(torch.float32)
-    union = area_a.to(torch.float32).unsqueeze(1) + area_b.to(torch.float32).unsqueeze(0) - inter
-    return (inter / union).T
+def _iou(inter: np.ndarray, area_a: np.ndarray, area_b: np.ndarray) -> np.ndarray:
+    """calculate_iou_between_stages R:69-90 from integer intersections: (m, n) float32.  NumPy float32 arithmetic is
+    the same IEEE arithmetic as the reference's float32 tensors (exact integers, one subtraction, one division)."""
+    inter = inter.astype(np.float32)
+    union = area_a.astype(np.float32)[:, None] + area_b.astype(np.float32)[None, :] - inter
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (inter / union).T
 
 
 @dataclasses.dataclass
 class _SceneState:
     scene_id: str
     n_points: int
-    ious: object                 # tensor (m,) or []
+    ious: object                 # float32 array (m,) or []
     sims: list
     matched1: Optional[torch.Tensor]   # bit rows (m, nw)
     stage2_rows: Optional[torch.Tensor]
@@ -162,7 +164,7 @@ class _SceneState:
 def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: TextSimilarity, device) -> _SceneState:
     pre = stage2.prefetch if isinstance(stage2, Stage2Result) else None
     if pre is not None and pre["stage1"] is stage1:
-        s1, n, s1_labels = pre["s1"], stage1.n_points, stage1.labels     # decoded by projection_back, still untouched
+        s1, n, s1_labels = pre["s1"], stage1.n_points, stage1.labels     # decoded by the projection stage, still untouched
         stage2.prefetch = None                                            # pass 1 edits s1 in place: single use
     else:
         pre = None
@@ -175,66 +177,69 @@ def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: Text
 
     # one read-back for everything pass 1 needs from the device: areas, stage-1 x stage-2 intersections, and
     # the stage-1 x stage-1 intersections (so the duplicate test R:217 needs no second round trip) -- or none at
-    # all when the projection stage already fetched them (Stage2Result.prefetch)
+    # all when the projection stage already fetched them (Stage2Result.prefetch).  The bookkeeping below runs on
+    # NumPy arrays and python lists: K is tens of rows, a tensor op per element would cost more than the kernels.
     if pre is not None:
-        area1, area2, inter, inter11 = (torch.from_numpy(pre[k]) for k in ("area1", "area2", "inter", "inter11"))
+        area1, area2, inter, inter11 = (pre[k] for k in ("area1", "area2", "inter", "inter11"))
     else:
-        area1, area2, inter, inter11 = (torch.from_numpy(a) for a in
-                                        _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2),
-                                                   _lib.cross_popcount(s1, s2), _lib.cross_popcount(s1, s1)))
+        area1, area2, inter, inter11 = _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2),
+                                                  _lib.cross_popcount(s1, s2), _lib.cross_popcount(s1, s1))
     iou = _iou(inter, area1, area2)                                                 # R:208  (K, S1)
-    best = torch.argmax(iou, dim=1)                                                 # R:211
+    best = np.argmax(iou, axis=1)                                                   # R:211 (first maximum, NaN counts as one)
     m_iou = _iou(inter11[best][:, best], area1[best], area1[best])                  # R:217
     k = len(best)
-    m_iou[range(k), range(k)] = 0                                                   # R:221
-    m_adj = (m_iou > cfg.stage1_iou_thres).to(int)                                  # R:224
+    np.fill_diagonal(m_iou, 0)                                                      # R:221
+    m_adj = (m_iou > cfg.stage1_iou_thres).tolist()                                 # R:224 (float32 against the python scalar)
+    best_l = best.tolist()
 
     chosen, ops = [], []                                                            # R:230-249
     absorbed_by = [-1] * k
     for i in range(k):
         if absorbed_by[i] != -1:
-            chosen.append(int(best[absorbed_by[i]]))
+            chosen.append(best_l[absorbed_by[i]])
             continue
-        chosen.append(int(best[i]))
-        if m_adj[i].sum() > 0:
+        chosen.append(best_l[i])
+        row = m_adj[i]
+        if any(row):
             for j in range(k):
-                if m_adj[i][j] == 1:
+                if row[j]:
                     absorbed_by[j] = i
-                    ops.append((1, int(best[i]), int(best[j])))                     # R:248 in-place OR
+                    ops.append((1, best_l[i], best_l[j]))                           # R:248 in-place OR
     if ops:
         _lib.apply_row_ops(s1, _lib.upload(np.asarray(ops, dtype=np.int32), torch.int32, device))
 
     # R:258-281: stage-2 masks matched to the same stage-1 mask are merged; each current row is
     # tracked as the list of original stage-2 rows it is the OR of
-    chosen_t = torch.tensor(chosen)
     parts = [[i] for i in range(k)]
-    uniq, cnt = torch.unique(chosen_t, return_counts=True)
-    for u, c in zip(uniq, cnt):
-        if c > 1:
-            sel = chosen_t == u
-            mconf = conf2[sel].mean()
-            merged = [p for keep, part in zip(sel.tolist(), parts) if keep for p in part]
-            parts = [part for keep, part in zip(sel.tolist(), parts) if not keep] + [merged]
-            conf2 = torch.cat([conf2[~sel], mconf.unsqueeze(0)])
-            chosen_t = torch.cat([chosen_t[~sel], u.unsqueeze(0)])
-    regrouped = any(len(p) > 1 for p in parts) or len(parts) != k
-    if regrouped:
+    regrouped = False
+    if len(set(chosen)) != k:                                                       # some stage-1 mask was chosen twice
+        chosen_t = torch.tensor(chosen)
+        uniq, cnt = torch.unique(chosen_t, return_counts=True)
+        for u, c in zip(uniq, cnt):
+            if c > 1:
+                sel = chosen_t == u
+                mconf = conf2[sel].mean()                                           # in the confidence dtype, as R:270
+                merged = [p for keep, part in zip(sel.tolist(), parts) if keep for p in part]
+                parts = [part for keep, part in zip(sel.tolist(), parts) if not keep] + [merged]
+                conf2 = torch.cat([conf2[~sel], mconf.unsqueeze(0)])
+                chosen_t = torch.cat([chosen_t[~sel], u.unsqueeze(0)])
+        regrouped = True
         offs = np.zeros(len(parts) + 1, dtype=np.int32)
         np.cumsum([len(p) for p in parts], out=offs[1:])
         s2 = _lib.or_reduce_groups(s2, _lib.upload(offs, torch.int32, device),
                                    i32([p for part in parts for p in part]), max(len(p) for p in parts))
 
     if ops or regrouped:            # rows changed: recompute R:285-288; otherwise iou / best are what they were
-        area1, area2, inter = (torch.from_numpy(a) for a in
-                               _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2), _lib.cross_popcount(s1, s2)))
+        area1, area2, inter = _lib.fetch(_lib.popcount_rows(s1), _lib.popcount_rows(s2), _lib.cross_popcount(s1, s2))
         iou = _iou(inter, area1, area2)                                             # R:285
-        best = torch.argmax(iou, dim=1)                                             # R:288
-    best_l = best.tolist()
-    other = [i for i, lab in enumerate(s1_labels) if lab == query_us and i not in best_l]   # R:293
+        best = np.argmax(iou, axis=1)                                               # R:288
+        best_l = best.tolist()
+    taken = set(best_l)
+    other = [i for i, lab in enumerate(s1_labels) if lab == query_us and i not in taken]    # R:293
     labels = [s1_labels[i] for i in best_l]                                         # R:297
     sims = sim.similarities(text_prompt, labels)                                    # R:299-302
-    return _SceneState(scene_id, n, iou[range(len(best)), best], sims,
-                       _lib.gather_rows(s1, _lib.upload(best, torch.int32, device)), s2, conf2,
+    return _SceneState(scene_id, n, iou[np.arange(len(best_l)), best], sims,
+                       _lib.gather_rows(s1, i32(best_l)), s2, conf2,
                        _lib.gather_rows(s1, i32(other)) if other else s1[:0])
 
 
@@ -270,26 +275,27 @@ def sim_threshold(all_sims: Sequence[Sequence[float]], percentile: float) -> flo
 def _pass2_scene(st: _SceneState, cfg, text_prompt, sim_thres) -> FinalResult:
     """R:330-428 for one scene."""
     dev = st.other1.device
-    pieces, conf, cls = [], [], []
+    pieces, cls = [], []
     n_other = st.other1.shape[0]
     if n_other:                                                                     # R:340-343
         pieces.append(st.other1)
-        conf += [torch.tensor(0.5)] * n_other
         cls += [text_prompt] * n_other
+    half = [torch.tensor(0.5)] * n_other
     if len(st.ious) == 0:                                                           # R:348-358
         if n_other == 0:
             return FinalResult(st.scene_id, st.n_points, None, [], [])
-        return FinalResult(st.scene_id, st.n_points, st.other1, torch.stack(conf), cls)
-    take1, take2 = [], []
-    order = []                                  # (source, index) in output order
-    for m, v in enumerate(st.ious):                                                 # R:360-392
-        if v > cfg.refiment_iou_thres:
-            if st.sims[m] < sim_thres:
+        return FinalResult(st.scene_id, st.n_points, st.other1, torch.stack(half), cls)
+    order, kept = [], []                        # (source, index) in output order; stage-2 rows whose confidence is kept
+    thr = np.float32(cfg.refiment_iou_thres)    # float32 tensor element against the python scalar (R:362)
+    sims = st.sims
+    for m, v in enumerate(st.ious.tolist() if hasattr(st.ious, "tolist") else st.ious):    # R:360-392
+        if np.float32(v) > thr:
+            if sims[m] < sim_thres:
                 continue
             order.append((1, m))
         else:
             order.append((2, m))
-        conf.append(st.stage2_conf[m])
+        kept.append(m)
         cls.append(text_prompt)
     if n_other == 0 and not order:                                                  # R:402-409
         return FinalResult(st.scene_id, st.n_points, None, [], [])
@@ -299,7 +305,11 @@ def _pass2_scene(st: _SceneState, cfg, text_prompt, sim_thres) -> FinalResult:
         idx = _lib.upload(np.asarray([m if src == 1 else k + m for src, m in order], dtype=np.int32), torch.int32, dev)
         pieces.append(_lib.gather_rows(both, idx))
     rows = torch.cat(pieces) if len(pieces) > 1 else pieces[0]
-    return FinalResult(st.scene_id, st.n_points, rows, torch.stack(conf), cls)       # R:411-412
+    # R:412 torch.stack of 0-d tensors: the 0.5 of the "other" masks is float32, the rest keeps the stage-2 dtype;
+    # stack of mixed dtypes promotes, exactly what cat of the two typed vectors does
+    conf_kept = st.stage2_conf[torch.as_tensor(kept, dtype=torch.long)] if kept else st.stage2_conf[:0]
+    conf = torch.cat([torch.stack(half), conf_kept]) if n_other else conf_kept
+    return FinalResult(st.scene_id, st.n_points, rows, conf, cls)                   # R:411-412
 
 
 def refine_class(scenes, cfg, text_prompt: str, sim: TextSimilarity, device="cuda",

@@ -245,14 +245,16 @@ int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int32_t *group_
 int bff_group_conf_mean(const void *conf, int32_t dtype, const int32_t *group_offs, const int32_t *members,
                         int32_t n_groups, void *mean, void *stream);
 
-/* a16 + a14 + the two popcounts around them, fused for k <= bff_resolve_overlaps_max_rows() (64) rows:
+/* a16 + a14 + the two popcounts around them, fused for k <= bff_resolve_overlaps_max_rows() (256) rows:
  *   before[i] = inter[i][i]                                   (row popcounts before any edit, P:592)
  *   solve_overlapping P:285-299 on `rows` in place: pairs (i < j) with inter[i][j] > 0 in the reference's order,
  *     the row merged from fewer raw masks (size[], ties: row i) loses the points of the other;
  *   rows[i] &= keep (P:595; keep may be NULL);  after[i] = popcount(rows[i])  (P:596).
  * inter = bff_cross_popcount(rows, rows) taken BEFORE the call (int32 [k][k]). */
 int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const int32_t *inter, const int32_t *size,
-                         const uint64_t *keep, int32_t *before, int32_t *after, void *stream);
+                         const uint64_t *keep, int32_t *before, int32_t *after, uint64_t *pair_masks, void *stream);
+/* pair_masks: device scratch, uint64 [bff_resolve_overlaps_scratch_words()] (the pair flags of P:289-292 as bit masks). */
+int64_t bff_resolve_overlaps_scratch_words(void);
 int bff_resolve_overlaps_max_rows(void);
 
 /* a16/a20: sequential row program applied independently to every word column.
@@ -383,11 +385,11 @@ int bff_cosine_rows(const void *a, int32_t na, const void *b, int32_t nb, int32_
  * K > cap, bit 1: min_members <= 0 and empty components exist -- both: use the host path), largest group, number of
  * 32-member slices}; sizes[cap], first[cap] (= smallest member = where the group's label comes from), offs[cap+1],
  * members[n_rows] (ascending inside a group), slices[3 * bff_group_slice_cap(n_rows, cap)] (work items of
- * bff_or_reduce_grouped); count: scratch int32 [n_rows]. */
+ * bff_or_reduce_grouped); count: scratch int32 [n_rows] (count_is_zero != 0: the caller has cleared it). */
 int32_t bff_group_slice_cap(int32_t n_rows, int32_t cap);
 int bff_group_components(const int32_t *comp, const int32_t *area, int32_t n_rows, float iou_thres,
-                         int32_t min_members, int32_t cap, int32_t *count, int32_t *info, int32_t *sizes,
-                         int32_t *first, int32_t *offs, int32_t *members, int32_t *slices, void *stream);
+                         int32_t min_members, int32_t cap, int32_t *count, int32_t count_is_zero, int32_t *info,
+                         int32_t *sizes, int32_t *first, int32_t *offs, int32_t *members, int32_t *slices, void *stream);
 /* bff_or_reduce_groups for those groups: out [cap][nw] (zeroed here; rows >= K stay zero), conf_mean [cap] in the
  * confidence dtype. */
 int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n_rows, const int32_t *info, int32_t cap,
@@ -396,13 +398,15 @@ int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n_rows, cons
 /* bff_resolve_overlaps with the row count on the device (*k_dev <= k_cap, else nothing is touched); inter is
  * [k_cap][k_cap]. */
 int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *inter, const int32_t *size,
-                             const uint64_t *keep, int32_t *before, int32_t *after, const int32_t *k_dev, void *stream);
+                             const uint64_t *keep, int32_t *before, int32_t *after, uint64_t *pair_masks,
+                             const int32_t *k_dev, void *stream);
 /* out[r] bit perm[s] = in[r] bit s, set bits only (undoes the spatial point sort by scatter: aggregated rows are
  * sparse); out must be zero; rows >= *k_dev (when given) are skipped. */
 int bff_scatter_bits(const uint64_t *rows_in, int32_t n_rows, int64_t nw_in, const int32_t *perm, int64_t n,
                      int64_t nw_out, uint64_t *rows_out, const int32_t *k_dev, void *stream);
 /* bff_cross_popcount when only the first *k_dev rows of b's leading `lead` rows (and of a, with limit_a) are
- * non-zero: tiles inside the zero part are skipped; inter is zeroed first. */
+ * non-zero: tiles inside the zero part are skipped; inter is zeroed first.  limit_a == 2: a and b are the same rows and
+ * only entries inter[i][j] with j >= i (up to tile granularity) are needed. */
 int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint64_t *b, int32_t nb, int64_t nw, int32_t *inter,
                            const int32_t *k_dev, int32_t limit_a, int32_t lead, void *stream);
 /* bff_clear_flagged_chunks unless *veto != 0 (device flag). */
@@ -437,16 +441,20 @@ typedef struct bff_scene_params {
 } bff_scene_params;
 
 /* Scratch of bff_scene_project, allocated by the caller for the scene's sizes (beyond_fixed_forms_amd/pipeline.py).
- * `rows` must be all zero on entry; it is all zero again when the call's work has run on the fast path. */
+ * `rows` must be all zero on entry; it is all zero again when the call's work has run on the fast path.
+ * masked, viewed, count and chunk_mask must be ONE allocation in this order (`zero_bytes` bytes from `masked`): the call
+ * clears them with a single fill. */
 typedef struct bff_scene_workspace {
     void *maskbits; uint32_t *segmap;
     uint64_t *rows, *chunk_mask, *keep, *tile_mask, *agg, *both;
     int32_t *masked, *viewed, *sel_scratch, *area, *mean_word, *order, *parent, *comp, *count;
     int32_t *gmembers, *goffs, *slices, *inter;
+    uint64_t *pair_masks;           /* bff_resolve_overlaps_scratch_words() */
     float *vals, *vals_sorted;
     uint32_t *hist, *merge_scratch;
     int64_t *sig, *sig_keys, *sig_sorted;
     void *sort_temp; size_t sort_temp_bytes;
+    size_t zero_bytes;              /* size of the block masked | viewed | count | chunk_mask */
     int32_t *hdr;                   /* device, bff_scene_header_words(s1_rows) int32 */
     int32_t *hdr_host;              /* pinned host mirror of the same size */
 } bff_scene_workspace;
@@ -483,6 +491,10 @@ int bff_scene_project(const bff_scene *scene, const bff_scene_params *params, co
 int bff_cloud_layout(const double *pts, int64_t n, int64_t stride, int64_t n_pad, int32_t sort, double *soa,
                      int32_t *unsort, int32_t *perm, uint32_t *codes, double *box, void *temp, size_t *temp_bytes,
                      void *stream);
+
+/* Measurement aid: n_lanes lanes each read one float at element lane * stride of src (every element once per launch)
+ * -- a gather with a known number of distinct cache lines, to calibrate the FETCH_SIZE counter (scripts/diag_membw.py). */
+int bff_diag_gather(const float *src, int64_t n_lanes, int64_t stride, float *out, void *stream);
 
 #ifdef __cplusplus
 }
