@@ -240,6 +240,35 @@ def merge_traffic(ds, cfg, dev):
     return dict(tile_pairs=v[0], chunk_visits=v[1], candidate_pairs=v[2], unions=v[3])
 
 
+def compulsory_traffic(ds, dev):
+    """Bytes the sweep HAS to move from HBM (measured on the device, outside the timed region): every 128-byte line
+    of the depth images and of the mask-word images that some point's gather touches, once (bff_diag_sweep_lines);
+    the cloud once per tile of 8 frames (xyz stays in registers across a tile); the two counters read+written once.
+    Re-fetches of a line by other waves (served by L2 / Infinity Cache or not) are what `traffic` has on top."""
+    import ctypes
+    n, hw = ds.n_points, ds.height * ds.width
+    n_mviews = ds.view_mask_offs.shape[0] - 1
+    maskbits = torch.empty((n_mviews, hw), device=dev, dtype=torch.int32 if ds.word_bits == 32 else torch.int64)
+    segmap = torch.empty((n_mviews, _lib.segmap_words(hw)), dtype=torch.int32, device=dev)
+    _lib.rle_to_maskbits(ds.run_start, ds.run_end, ds.mask_run_offs, ds.view_mask_offs, n_mviews, hw, ds.word_bits,
+                         maskbits, segmap)
+    del maskbits
+    line_words = (((hw + 15) // 16 + 31) // 32 + 1) // 2 * 2
+    dl = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
+    ml = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
+    k = (ctypes.c_double * 9)(*[float(v) for v in ds.cam_intr.reshape(-1)])
+    _lib.call("bff_diag_sweep_lines", _lib._ptr(ds.xyz), n, ds.xyz.shape[1], _lib._ptr(ds.inv_pose), ctypes.cast(k, ctypes.c_void_p),
+              ds.n_frames, _lib._ptr(ds.depth), _lib._ptr(ds.depth_index), ds.height, ds.width, 0.08, _lib._ptr(segmap),
+              ds.word_bits, _lib._ptr(ds.frame_mask), _lib._ptr(dl), _lib._ptr(ml), line_words)
+    count = lambda t: int(_lib.popcount_rows(t.view(torch.int64)).sum().item())
+    depth_lines, mask_lines = count(dl), count(ml)
+    tiles = (ds.n_frames + 7) // 8
+    xyz_bytes, counter_bytes = 24 * n * tiles, 16 * n
+    return {"bytes": 128 * (depth_lines + mask_lines) + xyz_bytes + counter_bytes,
+            "depth_lines_128B": depth_lines, "mask_word_lines_128B": mask_lines, "xyz_bytes (once per 8-frame tile)": xyz_bytes,
+            "counter_bytes": counter_bytes}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -405,6 +434,12 @@ def main():
             with open(tfile) as f:
                 traffic = json.load(f).get(f"project_views_{args.shape}")
         mt = merge_traffic(ds, cfg, dev)
+        comp = compulsory_traffic(ds, dev)
+        t_alone = sq["project_views"][2] * 1e-3
+        comp.update(achieved=comp["bytes"] / t_alone / 1e9, frac=comp["bytes"] / t_alone / 1e9 / HBM_PEAK_GBS,
+                    note="HBM bytes the sweep cannot avoid (each touched 128-B line once, cloud once per frame tile) over its "
+                         "duration alone on the chip; `achieved`/`frac` above use SURVEY 8(d)'s algorithmic bytes, which "
+                         "charge 28 B per (frame, point) even where caches serve them")
         mc_ms, mc_alone = ks["merge_components"][2], sq["merge_components"][2]
         l2_bytes = mt["chunk_visits"] * 128 * 64            # every visited chunk: 128 rows x 8 words staged through LDS
         out = {
@@ -426,6 +461,7 @@ def main():
                          "traffic_detail": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": pv[2], "launches": pv[0],
                          "survey_row_write_bytes_not_credited": zbytes,
+                         "compulsory": comp,
                          "alone_on_chip": {"avg_launch_ms": sq["project_views"][2],
                                            "achieved": abytes / (sq["project_views"][2] * 1e-3) / 1e9,
                                            "frac": abytes / (sq["project_views"][2] * 1e-3) / 1e9 / HBM_PEAK_GBS}},

@@ -89,12 +89,16 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_strip_kernel(const _Float
             half8 v = zero;
             if (j0 + row < nb) v = *reinterpret_cast<const half8 *>(b + (int64_t)(j0 + row) * dim + kc + 8 * seg);
             *reinterpret_cast<half8 *>(sb + (size_t)row * kStripPitch + 8 * seg) = v;
-            float q = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) q = fmaf((float)v[e], (float)v[e], q);
-            atomicAdd(&s_nb[row], q);
         }
         __syncthreads();
+        if (norm_b)                                                // squared norms of the staged piece: wave w takes rows w, w + 4, ...
+            for (int row = wave; row < kStrip; row += 4) {
+                float q = 0.f;
+                for (int k = lane; k < kn; k += 64) { const float x = (float)sb[(size_t)row * kStripPitch + k]; q = fmaf(x, x, q); }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) q += __shfl_xor(q, d);
+                if (lane == 0) s_nb[row] += q;
+            }
         for (int k0 = 0; k0 < kn; k0 += 32) {
             const half8 fa = ra ? *reinterpret_cast<const half8 *>(pa + kc + k0) : zero;
 #pragma unroll
@@ -106,6 +110,7 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_strip_kernel(const _Float
             }
         }
     }
+    __syncthreads();                                               // the bank norms of the last piece, written by other waves
     sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);           // the four k-quarters of a row: lanes r, r+16, r+32, r+48
 #pragma unroll
     for (int t = 0; t < kStripTiles; ++t) {

@@ -213,6 +213,42 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
     }
 }
 
+// Measurement aid: which 128-byte lines of the depth images and of the mask-word images does one sweep touch?
+// One thread per (frame, point) recomputes the pixel with the sweep's own arithmetic and marks bit (pixel / ppl) of the
+// frame's bitmap (ppl = pixels per 128-B line: 32 for float depth and 32-bit mask words, 16 for 64-bit words); the
+// caller counts the bits.  The COMPULSORY HBM traffic of the sweep is 128 B per marked line (each line has to come
+// in at least once; everything beyond that is re-fetching), plus the cloud once per frame tile and the counters.
+template <typename WordT>
+__global__ void sweep_lines_kernel(const double *__restrict__ xyz, int64_t n_points, int64_t n_pad,
+                                   const double *__restrict__ inv_pose, Intrinsics K, int n_frames,
+                                   const float *__restrict__ depth, const int32_t *__restrict__ depth_index, int H, int W,
+                                   double thresh, const uint32_t *__restrict__ segmap, int64_t seg_words,
+                                   const int32_t *__restrict__ frame_mask, uint32_t *__restrict__ depth_lines,
+                                   uint32_t *__restrict__ mask_lines, int64_t line_words)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (n >= n_points) return;
+    const double px = xyz[n], py = xyz[n_pad + n], pz = xyz[2 * n_pad + n];
+    const double *P = inv_pose + 16 * (int64_t)f;
+    const double cx = fma(P[3], 1.0, fma(P[2], pz, fma(P[1], py, fma(P[0], px, 0.0))));
+    const double cy = fma(P[7], 1.0, fma(P[6], pz, fma(P[5], py, fma(P[4], px, 0.0))));
+    const double cz = fma(P[11], 1.0, fma(P[10], pz, fma(P[9], py, fma(P[8], px, 0.0))));
+    const double p0 = fma(K.k[2], cz, fma(K.k[1], cy, fma(K.k[0], cx, 0.0)));
+    const double p1 = fma(K.k[5], cz, fma(K.k[4], cy, fma(K.k[3], cx, 0.0)));
+    const double u = rint(p0 / cz), v = rint(p1 / cz);
+    if (!((u >= 0.0) && (u < (double)W) && (v >= 0.0) && (v < (double)H))) return;
+    const int pix = (int)v * W + (int)u;
+    const int dl = pix >> 5;                                            // 32 floats per 128-B line
+    atomicOr(depth_lines + (int64_t)f * line_words + (dl >> 5), 1u << (dl & 31));
+    const float d = depth[(int64_t)depth_index[f] * H * W + pix];
+    const int mi = frame_mask ? frame_mask[f] : -1;
+    if (mi < 0 || d == 0.0f || !(fabs(cz - (double)d) < thresh)) return;
+    if (segmap && !((segmap[(int64_t)mi * seg_words + (pix >> 12)] >> ((pix >> 7) & 31)) & 1)) return;
+    const int ml = pix / (int)(128 / sizeof(WordT));
+    atomicOr(mask_lines + (int64_t)f * line_words + (ml >> 5), 1u << (ml & 31));
+}
+
 // Bounding boxes of the sweep's point tiles (one wave of project_views_kernel = kPPT words = 256 consecutive points
 // of the spatially sorted cloud): bounds[t] = (xmin, ymin, zmin, xmax, ymax, zmax).  NaN coordinates are ignored
 // (such a point is never in bounds), an empty tile gives (+inf, -inf) and is never culled.
@@ -508,3 +544,27 @@ extern "C" int bff_point_tile_bounds(const double *xyz, int64_t n_points, int64_
 }
 
 extern "C" int bff_point_tile_size(void) { return kPPT * kWave; }
+
+// Marks the 128-byte lines one sweep touches (see sweep_lines_kernel).  depth_lines / mask_lines: uint32
+// [n_frames][line_words] bitmaps, zeroed by the caller, line_words >= ceil(ceil(H*W / 16) / 32).
+extern "C" int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
+                                    const double *cam_intr_host, int32_t n_frames, const float *depth,
+                                    const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
+                                    const uint32_t *segmap, int32_t word_bits, const int32_t *frame_mask,
+                                    uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words, void *stream)
+{
+    BFF_REQUIRE(xyz && inv_pose && cam_intr_host && depth && depth_index && depth_lines && mask_lines && n_points > 0 &&
+                n_frames > 0 && (word_bits == 32 || word_bits == 64), "bff_diag_sweep_lines: bad arguments");
+    BFF_LIMIT(n_frames <= 65535, "bff_diag_sweep_lines: too many frames");
+    Intrinsics K;
+    for (int i = 0; i < 9; ++i) K.k[i] = cam_intr_host[i];
+    const int64_t seg_words = ceil_div(ceil_div((int64_t)height * width, 128), 32);
+    dim3 grid((unsigned)ceil_div(n_points, 256), (unsigned)n_frames);
+    if (word_bits == 32)
+        sweep_lines_kernel<uint32_t><<<grid, 256, 0, as_stream(stream)>>>(xyz, n_points, n_pad, inv_pose, K, n_frames, depth,
+            depth_index, height, width, depth_thresh, segmap, seg_words, frame_mask, depth_lines, mask_lines, line_words);
+    else
+        sweep_lines_kernel<uint64_t><<<grid, 256, 0, as_stream(stream)>>>(xyz, n_points, n_pad, inv_pose, K, n_frames, depth,
+            depth_index, height, width, depth_thresh, segmap, seg_words, frame_mask, depth_lines, mask_lines, line_words);
+    return launched("bff_diag_sweep_lines");
+}

@@ -1161,8 +1161,18 @@ __global__ __launch_bounds__(64) void group_conf_mean_kernel(const T *__restrict
 //   info[3] = number of 32-member slices of the kept groups (work items of bff_or_reduce_grouped).
 __global__ void group_count_kernel(const int32_t *__restrict__ comp, int n, int32_t *__restrict__ count)
 {
+    // 64 consecutive rows (two views' masks) belong to a handful of components: one atomic per distinct root of the
+    // wave instead of one per row (thousands of rows share a few dozen counters)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(count + comp[i], 1);
+    const int root = i < n ? comp[i] : -1;
+    uint64_t todo = __ballot(root >= 0);
+    while (todo) {
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const int r = __shfl(root, leader);
+        const uint64_t same = __ballot(root == r);
+        if (lane_id() == leader) atomicAdd(count + r, __popcll(same));
+        todo &= ~same;
+    }
 }
 
 __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restrict__ comp, const int32_t *__restrict__ count,
@@ -1777,9 +1787,12 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
         uint64_t *pass2 = reinterpret_cast<uint64_t *>((p2 + 7) & ~(uintptr_t)7);
         tile_masks_kernel<<<nt, 256, 0, st>>>(chunk_mask, order, n_order, mw, tile_mask, hist, hist_sorted, (int)n_pos, area,
                                              tile_hmax, tile_amin, label_id, row_sorted, area_sorted, label_sorted);
-        static const int kStrides = [] {                               // 1, 2, 3, 5 (more strides measured no faster)
-            const char *e = getenv("BFF_SKELETON_STRIDES");            // experiment knob: 0 switches the pre-pass off
-            const int v = e ? atoi(e) : 4;
+        // Pre-pass over pairs 1, 2, 3, 5 apart in the tile order: it used to shorten the tile pass when every proven
+        // edge went into the global forest at once; with local sets and early settling inside the tiles it no
+        // longer pays (config 2, 4 rotating scenes: 754 scenes/s with 4 strides, 768 without) -> off unless asked for.
+        static const int kStrides = [] {
+            const char *e = getenv("BFF_SKELETON_STRIDES");
+            const int v = e ? atoi(e) : 0;
             return v < 0 ? 0 : (v > 8 ? 8 : v);
         }();
         if (kStrides > 0) {

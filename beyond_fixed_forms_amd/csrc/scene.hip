@@ -75,11 +75,17 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
                               ws->chunk_mask, ws->masked, ratio ? ws->viewed : nullptr, sc->tile_bounds, stream));
     // a14 / a15: point filter, threshold stays on the device (header words 2, 3 = n_unique, thr)
     if (pr->filter_mode != 0) {
-        BFF_TRY(bff_point_values(ws->masked, ratio ? ws->viewed : nullptr, n, ws->vals, stream));
-        size_t tb = ws->sort_temp_bytes;
-        BFF_TRY(bff_sort_f32(ws->vals, ws->vals_sorted, n, ws->sort_temp, &tb, stream));
-        BFF_TRY(bff_select_unique_rank(ws->vals_sorted, n, pr->filter_fraction, ws->sel_scratch,
-                                       reinterpret_cast<float *>(hdr + BFF_HDR_THR), hdr + BFF_HDR_NUNIQUE, stream));
+        if (pr->filter_sort) {          // the general formulation: sort all n values (scenes with > 2^18 distinct ones)
+            BFF_TRY(bff_point_values(ws->masked, ratio ? ws->viewed : nullptr, n, ws->vals, stream));
+            size_t tb = ws->sort_temp_bytes;
+            BFF_TRY(bff_sort_f32(ws->vals, ws->vals_sorted, n, ws->sort_temp, &tb, stream));
+            BFF_TRY(bff_select_unique_rank(ws->vals_sorted, n, pr->filter_fraction, ws->sel_scratch,
+                                           reinterpret_cast<float *>(hdr + BFF_HDR_THR), hdr + BFF_HDR_NUNIQUE, stream));
+        } else {                        // the statistic is a function of (masked, viewed): distinct pairs, no sort
+            BFF_TRY(bff_point_threshold_pairs(ws->masked, ratio ? ws->viewed : nullptr, n, pr->filter_fraction,
+                                              ws->pair_scratch, reinterpret_cast<float *>(hdr + BFF_HDR_THR),
+                                              hdr + BFF_HDR_NUNIQUE, hdr + BFF_HDR_OVERFLOW, stream));
+        }
         BFF_TRY(bff_ratio_keep(ws->masked, ratio ? ws->viewed : nullptr, n, 0.0f,
                                reinterpret_cast<const float *>(hdr + BFF_HDR_THR), 1, nw, ws->keep, stream));
     } else {

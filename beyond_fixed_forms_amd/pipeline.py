@@ -16,7 +16,7 @@ import torch
 from . import _lib
 
 GROUP_CAP = 256
-HDR_K, HDR_NUNIQUE, HDR_THR = 0, 4, 5
+HDR_K, HDR_NUNIQUE, HDR_THR, HDR_OVERFLOW = 0, 4, 5, 6
 HDR_SIZES, HDR_FIRST, HDR_BEFORE, HDR_AFTER, HDR_CONF, HDR_CROSS = (16 + k * GROUP_CAP for k in range(6))
 
 
@@ -36,12 +36,12 @@ class SceneStruct(ctypes.Structure):
 
 class ParamsStruct(ctypes.Structure):
     _fields_ = [("depth_thresh", c_double), ("filter_fraction", c_double), ("iou_thres", c_float),
-                ("min_members", c_int32), ("filter_mode", c_int32), ("pad_", c_int32)]
+                ("min_members", c_int32), ("filter_mode", c_int32), ("filter_sort", c_int32)]
 
 
 _WS_PTRS = ["maskbits", "segmap", "rows", "chunk_mask", "keep", "tile_mask", "agg", "both",
             "masked", "viewed", "sel_scratch", "area", "mean_word", "order", "parent", "comp", "count",
-            "gmembers", "goffs", "slices", "inter", "pair_masks", "vals", "vals_sorted", "hist", "merge_scratch",
+            "gmembers", "goffs", "slices", "inter", "pair_masks", "pair_scratch", "vals", "vals_sorted", "hist", "merge_scratch",
             "sig", "sig_keys", "sig_sorted", "sort_temp"]
 
 
@@ -96,9 +96,10 @@ def scene_struct(ds, stage1=None, n_frames=None):
     return s
 
 
-def params_struct(cfg, depth_thresh):
+def params_struct(cfg, depth_thresh, filter_sort=False):
     _check_layout()
     p = ParamsStruct()
+    p.filter_sort = 1 if filter_sort else 0
     ratio = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
     p.depth_thresh = float(depth_thresh)
     p.filter_mode = 1 if cfg.if_occurance_threshold else (2 if ratio else 0)
@@ -172,6 +173,7 @@ class SceneWorkspace:
         self._need("agg", GROUP_CAP * nw, i64)
         self._need("sel_scratch", (n + 1023) // 1024, i32)
         self._need("pair_masks", int(lib.bff_resolve_overlaps_scratch_words()), i64)
+        self._need("pair_scratch", int(lib.bff_point_threshold_scratch_words()), i32)
         for k in ("area", "mean_word", "order", "parent", "comp", "gmembers"):
             self._need(k, n_rows, i32)
         self._need("goffs", GROUP_CAP + 1, i32)
@@ -218,10 +220,11 @@ def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
         ws.rows_dirty = False
     both = torch.empty((GROUP_CAP + s1_rows, ds.nw), dtype=torch.int64, device=dev)     # outlives the workspace's reuse
     ws.struct.both = c_void_p(both.data_ptr())
-    pr = params_struct(cfg, depth_thresh)
+    pr = params_struct(cfg, depth_thresh, filter_sort=bool(ds.__dict__.get("_filter_sort", False)))
     ws.in_flight = True
     _lib.call("bff_scene_project", ctypes.byref(sc), ctypes.byref(pr), ctypes.byref(ws.struct))
-    return dict(ws=ws, both=both, s1_rows=s1_rows, params=pr, stream=torch.cuda.current_stream(dev))
+    return dict(ws=ws, both=both, s1_rows=s1_rows, params=pr, stream=torch.cuda.current_stream(dev),
+                args=(ds, cfg, depth_thresh, stage1, n_frames))
 
 
 def collect(h):
@@ -234,6 +237,16 @@ def collect(h):
     words = HDR_CROSS + h["s1_rows"] * (GROUP_CAP + h["s1_rows"])
     hdr = ws.hdr_host.numpy()[:words].copy()
     ws.in_flight = False
+    if hdr[HDR_OVERFLOW] != 0 and not h["params"].filter_sort:
+        # more distinct filter values than the pair formulation holds: everything after the sweep is void.  Run the
+        # scene again with the sorting formulation (and remember it for this scene).
+        ds = h["args"][0]
+        ds.__dict__["_filter_sort"] = True
+        ws.rows_dirty = True
+        with torch.cuda.stream(h["stream"]):
+            h2 = issue(*h["args"])
+        h.update(h2)
+        return collect(h)
     if hdr[HDR_K + 1] != 0:
         ws.rows_dirty = True                      # the general path reads the rows and clears them itself
     return hdr

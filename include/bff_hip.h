@@ -318,6 +318,13 @@ int bff_ids_to_rows(const int64_t *ids, int64_t n_points, const int64_t *values,
  * the threshold is read from thr_dev (device) when non-NULL, else the immediate `thr`; use_thr == 0 -> keep =
  * masked > 0. */
 int bff_point_values(const int32_t *masked, const int32_t *viewed, int64_t n_points, float *vals, void *stream);
+/* The same (thr, n_unique) without sorting n_points values: the statistic is a function of the integer pair (masked,
+ * viewed), of which a scene holds only ~10^3..10^4 different ones: mark the pairs, hash their float32 values into a set
+ * (= x.unique() of P:516 / P:574), radix-select the rank.  scratch: uint32 [bff_point_threshold_scratch_words()];
+ * *overflow (device, not cleared by the call) is set to 1 if the set (2^18 values) is full: use the sorting path then. */
+int64_t bff_point_threshold_scratch_words(void);
+int bff_point_threshold_pairs(const int32_t *masked, const int32_t *viewed, int64_t n_points, double fraction,
+                              uint32_t *scratch, float *thr, int32_t *n_unique, int32_t *overflow, void *stream);
 int bff_select_unique_rank(const float *sorted, int64_t n, double fraction, int32_t *block_scratch,
                            float *thr, int32_t *n_unique, void *stream);
 int bff_ratio_keep(const int32_t *masked, const int32_t *viewed, int64_t n_points, float thr,
@@ -437,7 +444,7 @@ typedef struct bff_scene_params {
     float iou_thres;
     int32_t min_members;            /* cfg.min_aggragated_masks */
     int32_t filter_mode;            /* 0 none, 1 occurrence (P:512-522), 2 detection ratio (P:524-578) */
-    int32_t pad_;
+    int32_t filter_sort;            /* != 0: threshold by sorting all values (after header word BFF_HDR_OVERFLOW was set) */
 } bff_scene_params;
 
 /* Scratch of bff_scene_project, allocated by the caller for the scene's sizes (beyond_fixed_forms_amd/pipeline.py).
@@ -450,6 +457,7 @@ typedef struct bff_scene_workspace {
     int32_t *masked, *viewed, *sel_scratch, *area, *mean_word, *order, *parent, *comp, *count;
     int32_t *gmembers, *goffs, *slices, *inter;
     uint64_t *pair_masks;           /* bff_resolve_overlaps_scratch_words() */
+    uint32_t *pair_scratch;         /* bff_point_threshold_scratch_words() */
     float *vals, *vals_sorted;
     uint32_t *hist, *merge_scratch;
     int64_t *sig, *sig_keys, *sig_sorted;
@@ -463,6 +471,8 @@ typedef struct bff_scene_workspace {
 #define BFF_HDR_K 0                 /* info[4] of bff_group_components: K, flags, largest group, slices */
 #define BFF_HDR_NUNIQUE 4           /* distinct filter values (0: the reference would raise IndexError) */
 #define BFF_HDR_THR 5               /* float32 threshold */
+#define BFF_HDR_OVERFLOW 6          /* != 0: more distinct filter values than bff_point_threshold_pairs holds: run the
+                                       scene again with params.filter_sort = 1 (everything after the sweep is void) */
 #define BFF_HDR_SIZES 16                              /* [cap] members per group */
 #define BFF_HDR_FIRST (16 + BFF_GROUP_CAP)            /* [cap] smallest member of the group */
 #define BFF_HDR_BEFORE (16 + 2 * BFF_GROUP_CAP)       /* [cap] popcount before overlap resolution (P:592) */
@@ -492,6 +502,14 @@ int bff_cloud_layout(const double *pts, int64_t n, int64_t stride, int64_t n_pad
                      int32_t *unsort, int32_t *perm, uint32_t *codes, double *box, void *temp, size_t *temp_bytes,
                      void *stream);
 
+/* Measurement aid: the 128-byte lines of the depth and mask-word images that one sweep touches, as bitmaps (uint32
+ * [n_frames][line_words], zeroed by the caller; line index = pixel / (pixels per 128 B)).  128 B per marked line is
+ * the sweep's compulsory HBM traffic for these images (bench.py: roofline.compulsory). */
+int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
+                         const double *cam_intr_host, int32_t n_frames, const float *depth, const int32_t *depth_index,
+                         int32_t height, int32_t width, double depth_thresh, const uint32_t *segmap, int32_t word_bits,
+                         const int32_t *frame_mask, uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words,
+                         void *stream);
 /* Measurement aid: n_lanes lanes each read one float at element lane * stride of src (every element once per launch)
  * -- a gather with a known number of distinct cache lines, to calibrate the FETCH_SIZE counter (scripts/diag_membw.py). */
 int bff_diag_gather(const float *src, int64_t n_lanes, int64_t stride, float *out, void *stream);

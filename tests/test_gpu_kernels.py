@@ -475,11 +475,40 @@ def test_point_filters(lib, mode, n):
     assert np.array_equal(unpack(keep0[None], n)[0], masked > 0)
     for f in (0.0, 0.999999, 1.0):          # first, last, out of range (python: IndexError)
         t2, _ = lib.point_threshold(md, vd, f)
+        t3, nu3, ovf = lib.point_threshold_pairs(md, vd, f)
         k = math.floor(f * uniq.shape[0])
+        assert int(ovf.item()) == 0 and int(nu3.item()) == uniq.shape[0]
         if k < uniq.shape[0]:
-            assert t2.cpu().numpy()[0] == uniq[k].numpy()
+            assert t2.cpu().numpy()[0] == uniq[k].numpy() and t3.cpu().numpy()[0] == uniq[k].numpy()
         else:
-            assert np.isnan(t2.cpu().numpy()[0])
+            assert np.isnan(t2.cpu().numpy()[0]) and np.isnan(t3.cpu().numpy()[0])
+    # the pair formulation (no sort): same threshold, same count, bit for bit
+    t3, nu3, ovf = lib.point_threshold_pairs(md, vd, frac)
+    assert int(ovf.item()) == 0 and int(nu3.item()) == uniq.shape[0] and t3.cpu().numpy()[0] == thr.numpy()
+
+
+def test_point_threshold_pairs_out_of_range_and_overflow(lib):
+    """Pairs outside the bitmap (masked >= 4096 or viewed >= 1024) go straight into the value set; more than 2^18
+    distinct values set the overflow flag (the caller then sorts)."""
+    import math
+    rng = np.random.default_rng(77)
+    n = 50_000
+    masked = rng.integers(0, 9000, n)
+    viewed = rng.integers(0, 3000, n)
+    md = torch.tensor(masked, dtype=torch.int32, device=DEV)
+    vd = torch.tensor(viewed, dtype=torch.int32, device=DEV)
+    stat = torch.tensor(masked, dtype=torch.float32) / (torch.tensor(viewed, dtype=torch.float32) + 1)
+    uniq = stat.unique()
+    for f in (0.0, 0.38, 0.77):
+        thr, nu, ovf = lib.point_threshold_pairs(md, vd, f)
+        assert int(ovf.item()) == 0 and int(nu.item()) == uniq.shape[0]
+        assert thr.cpu().numpy()[0] == uniq[math.floor(f * uniq.shape[0])].numpy()
+    big = torch.arange(300_000, dtype=torch.int32, device=DEV) + 5000          # 300k distinct values, all out of range
+    _, _, ovf = lib.point_threshold_pairs(big, None, 0.3)
+    assert int(ovf.item()) == 1
+    ok = torch.arange(200_000, dtype=torch.int32, device=DEV) + 5000           # 200k distinct values fit
+    thr, nu, ovf = lib.point_threshold_pairs(ok, None, 0.3)
+    assert int(ovf.item()) == 0 and int(nu.item()) == 200_000 and thr.cpu().numpy()[0] == np.float32(5000 + 60_000)
 
 
 @pytest.mark.parametrize("hs,ws,h,w", [(480, 640, 968, 1296), (48, 64, 97, 131), (120, 160, 120, 160), (100, 90, 37, 41)])
