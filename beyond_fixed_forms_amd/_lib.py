@@ -26,9 +26,9 @@ SIGNATURES = {
     "bff_point_tile_bounds": [_P, _L, _L, _P, _P],
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
-    "bff_row_stats": [_P, _I, _L, _P, _P, _P, _I, _P, _P, _P],
+    "bff_row_stats": [_P, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P],
     "bff_clear_flagged_chunks": [_P, _I, _L, _P, _P],
-    "bff_merge_components": [_P, _I, _L, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P],
+    "bff_merge_components": [_P, _I, _L, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P],
     "bff_merge_adjacency": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "bff_permute_bits": [_P, _I, _L, _P, _L, _L, _P, _P],
     "bff_components_round": [_P, _I, _P, _P, _P, _P],
@@ -256,9 +256,14 @@ class RowArena:
         self.busy = False
 
 
+last_chunk_pop = None     # per-chunk point counts of the latest row_stats call (merge_components' second-level bound)
+
+
 def row_stats(rows, cmask=None):
     """-> (area i32 [R], mean_word i32 [R], chunk_mask i64 [R][mw], hist i32 [R][64], signature i64 [R]).
-    cmask given (from project_views): only the flagged chunks are read."""
+    cmask given (from project_views): only the flagged chunks are read.  The per-chunk point counts of the rows
+    (uint16 [R][64 * mw], the second-level bound of merge_components) are kept in `hist.chunk_pop`."""
+    global last_chunk_pop
     n = rows.shape[0]
     given = cmask is not None
     area = torch.empty(n, dtype=i32, device=rows.device)
@@ -267,13 +272,15 @@ def row_stats(rows, cmask=None):
         cmask = chunk_mask_buffer(n, rows.shape[1], rows.device)
     hist = torch.empty((n, 64), dtype=i32, device=rows.device)
     sig = torch.empty(n, dtype=i64, device=rows.device)
+    cpop = torch.empty((n, cmask.shape[1] * 64), dtype=torch.int16, device=rows.device)
     call("bff_row_stats", _ptr(rows, i64), n, rows.shape[1], _ptr(area), _ptr(mean_word), _ptr(cmask, i64),
-         1 if given else 0, _ptr(hist), _ptr(sig))
+         1 if given else 0, _ptr(hist), _ptr(sig), _ptr(cpop))
+    hist.chunk_pop = cpop                        # travels with the histogram it refines
     return area, mean_word, cmask, hist, sig
 
 
 def merge_components(rows, area, label_id, iou_thres, order, chunk_mask, hist, diag=None, parent=None,
-                     coarse_stride=0):
+                     coarse_stride=0, use_chunk_bound=True):
     """comp[i] = smallest row index of the component of row i in the merge graph (no adjacency matrix).
     coarse_stride > 1 (optional, off by default: measured slower at config 2): the tile pass first runs on
     every coarse_stride-th row of `order`, then the full pass starts from that forest."""
@@ -286,10 +293,13 @@ def merge_components(rows, area, label_id, iou_thres, order, chunk_mask, hist, d
     comp = torch.empty(n, dtype=i32, device=rows.device)
     hist_sorted = torch.empty(int(load().bff_merge_scratch_words(n)), dtype=i32, device=rows.device)  # scratch, see bff_hip.h
 
+    cpop = getattr(hist, "chunk_pop", None) if use_chunk_bound else None
+
     def run(ordr, init_parent, out):
         call("bff_merge_components", _ptr(rows, i64), n, rows.shape[1], _ptr(ordr, i32), ordr.shape[0],
              _ptr(chunk_mask, i64), _ptr(tmask), _ptr(hist, i32), _ptr(hist_sorted), _ptr(area, i32),
-             _ptr(label_id, i32), float(iou_thres), _ptr(parent), int(init_parent), _ptr(out), _ptr(diag, i32))
+             _ptr(label_id, i32), float(iou_thres), _ptr(parent), int(init_parent), _ptr(out), _ptr(diag, i32),
+             _ptr(cpop, torch.int16))
 
     if init and coarse_stride > 1 and n >= 64 * coarse_stride:
         run(order[::coarse_stride].contiguous(), True, None)

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restri
                                                          int bin_words, int32_t *__restrict__ area,
                                                          int32_t *__restrict__ mean_word,
                                                          uint64_t *__restrict__ cmask, uint32_t *__restrict__ hist,
-                                                         int64_t *__restrict__ signature)
+                                                         int64_t *__restrict__ signature, uint16_t *__restrict__ cpop)
 {
     extern __shared__ uint64_t s_cm[];                 // mw words
     __shared__ int part[4];
@@ -171,6 +171,16 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t *__restri
     if (lane_id() == 0) { part[tid >> 6] = s; psum[tid >> 6] = ws; }
     __syncthreads();
     for (int i = tid; i < mw; i += 256) cmask[(int64_t)r * mw + i] = s_cm[i];
+    if (cpop) {                                    // points per 512-point chunk (second-level bound of the tile pass)
+        const int n_chunks = (int)((nw + kCW - 1) / kCW);
+        for (int c = tid; c < mw * 64; c += 256) {
+            int pc = 0;
+            if (c < n_chunks)
+#pragma unroll
+                for (int k = 0; k < kCW; ++k) { const int64_t w = (int64_t)c * kCW + k; if (w < nw) pc += popc64(row[w]); }
+            cpop[(int64_t)r * mw * 64 + c] = (uint16_t)pc;
+        }
+    }
     const int a_all = part[0] + part[1] + part[2] + part[3];
     if (tid < kBins) {
         hist[(int64_t)r * kBins + tid] = s_hist[tid];
@@ -193,7 +203,8 @@ __global__ __launch_bounds__(256) void row_stats_sparse_kernel(const uint64_t *_
                                                                 int mw, int bin_words, int32_t *__restrict__ area,
                                                                 int32_t *__restrict__ mean_word,
                                                                 const uint64_t *__restrict__ cmask,
-                                                                uint32_t *__restrict__ hist, int64_t *__restrict__ signature)
+                                                                uint32_t *__restrict__ hist, int64_t *__restrict__ signature,
+                                                                uint16_t *__restrict__ cpop)
 {
     __shared__ uint32_t s_hist[4][kBins];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -209,6 +220,7 @@ __global__ __launch_bounds__(256) void row_stats_sparse_kernel(const uint64_t *_
         const uint64_t m = cmask[(int64_t)r * mw + i];
         if ((m >> lane) & 1) {
             const int64_t w0 = ((int64_t)i * 64 + lane) * kCW;
+            int in_chunk = 0;
 #pragma unroll
             for (int k = 0; k < kCW; ++k) {
                 const int64_t w = w0 + k;
@@ -217,9 +229,11 @@ __global__ __launch_bounds__(256) void row_stats_sparse_kernel(const uint64_t *_
                     const int pc = popc64(v);
                     atomicAdd(&hs[(int)(w / bin_words)], (uint32_t)pc);
                     s += pc;
+                    in_chunk += pc;
                     ws += (unsigned long long)pc * (unsigned long long)w;
                 }
             }
+            if (cpop) cpop[(int64_t)r * mw * 64 + i * 64 + lane] = (uint16_t)in_chunk;     // unflagged chunks: zeroed by the caller
         }
     }
 #pragma unroll
@@ -739,7 +753,7 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
                                                 const int32_t *__restrict__ area_sorted,
                                                 const int32_t *__restrict__ label_sorted, float thr,
                                                 int32_t *__restrict__ parent, int n_tiles,
-                                                int32_t *__restrict__ diag)
+                                                int32_t *__restrict__ diag, const uint16_t *__restrict__ cpop)
 {
     __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
     __shared__ uint16_t clist[kMaxChunks];
@@ -840,20 +854,14 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
                 if ((labA[ti * 4 + r] == labB[tj * 4 + c]) && (iou > thr)) cand |= 1u << (4 * r + c);
             }
         }
-    const int any_candidate = __syncthreads_or(cand != 0);
+    int any_candidate = __syncthreads_or(cand != 0);
     if (kDiag) diag_lap(diag, 5, &t_lap);                                     // per-pair histogram bound
     if (!any_candidate) return;                                    // block-uniform
 
-    // ---- compact the candidate pairs of the tile: (row index in A) << 8 | (row index in B)
     __shared__ uint16_t plist[kT * kT];
     __shared__ int wbase[4];
     const int lane = tid & 63, wv = tid >> 6;
-    const int mine_n = __popc(cand);
-    int incl = mine_n;
-#pragma unroll
-    for (int q = 1; q < 64; q <<= 1) { const int up = __shfl_up(incl, q); if (lane >= q) incl += up; }
-    if (lane == 63) wbase[wv] = incl;
-    if (tid < kWave) {                                             // chunk list, meanwhile
+    if (tid < kWave) {                                             // chunks both tiles occupy
         int base = 0;
         for (int m = 0; m < (n_chunks + 63) / 64; ++m) {
             const uint64_t bits = tmask ? (tmask[(int64_t)bi * mw + m] & tmask[(int64_t)bj * mw + m]) : ~0ull;
@@ -865,6 +873,75 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
         }
         if (tid == 0) s_cnt = base;
     }
+    __syncthreads();
+    // ---- second-level bound, same expression with the 512-point chunks both tiles occupy as the bins:
+    // I(i, j) <= sum over shared chunks of min(points of i in the chunk, points of j in the chunk).  A bin of the
+    // first bound spans several thousand points; objects that are neighbours in space (or two groups of views of one
+    // object) share bins but far fewer points per chunk -- most surviving non-edges are decided here, for 2 bytes
+    // per (row, chunk) instead of the chunk's 64 bytes.
+    if (cpop && tmask) {
+        uint32_t (*pa2)[kT] = reinterpret_cast<uint32_t (*)[kT]>(&sa[0][0]);      // [chunk pair][row]: two chunks per word
+        uint32_t (*pb2)[kT] = reinterpret_cast<uint32_t (*)[kT]>(&sb[0][0]);
+        constexpr int kPairsPerStep = 64;                          // 128 chunks per step (16 KB per side)
+        const int cnt2 = s_cnt;
+        const int64_t cstride = (int64_t)mw * 64;
+        uint32_t ub2[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ub2[r][c] = 0;
+        for (int c0 = 0; c0 < cnt2; c0 += 2 * kPairsPerStep) {
+            const int n_here = min(2 * kPairsPerStep, cnt2 - c0), np_here = (n_here + 1) / 2;
+            // thread (row k of A or B, strided over chunk pairs): 2-byte gathers along the row's chunk table
+            for (int q = tid; q < np_here * 2 * kT; q += 256) {
+                const int kp = q / (2 * kT), rr = q % (2 * kT);
+                const int row = rr < kT ? rowA[rr] : rowB[rr - kT];
+                uint32_t v = 0;
+                if (row >= 0) {
+                    const uint16_t *t = cpop + (int64_t)row * cstride;
+                    const int s0 = c0 + 2 * kp;
+                    v = t[clist[s0]];
+                    if (s0 + 1 < cnt2) v |= (uint32_t)t[clist[s0 + 1]] << 16;
+                }
+                if (rr < kT) pa2[kp][rr] = v; else pb2[kp][rr - kT] = v;
+            }
+            __syncthreads();
+            if (cand)
+                for (int kp = 0; kp < np_here; ++kp) {
+                    uint32_t av[4], bv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { av[r] = pa2[kp][ti * 4 + r]; bv[r] = pb2[kp][tj * 4 + r]; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const us2 m = __builtin_elementwise_min(__builtin_bit_cast(us2, av[r]), __builtin_bit_cast(us2, bv[c]));
+                            ub2[r][c] = __builtin_amdgcn_udot2(m, ones, ub2[r][c], false);
+                        }
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (cand & (1u << (4 * r + c))) {
+                    const int ai = areaA[ti * 4 + r], aj = areaB[tj * 4 + c];
+                    const float fi = (float)min((int)ub2[r][c], min(ai, aj));
+                    const float iou = __fdiv_rn(fi, (float)ai + (float)aj - fi);
+                    if (!(iou > thr)) cand &= ~(1u << (4 * r + c));
+                }
+        any_candidate = __syncthreads_or(cand != 0);
+        if (kDiag) diag_lap(diag, 11, &t_lap);                                // chunk-level bound
+        if (!any_candidate) return;                                // block-uniform
+    }
+
+    // ---- compact the candidate pairs of the tile: (row index in A) << 8 | (row index in B)
+    const int mine_n = __popc(cand);
+    int incl = mine_n;
+#pragma unroll
+    for (int q = 1; q < 64; q <<= 1) { const int up = __shfl_up(incl, q); if (lane >= q) incl += up; }
+    if (lane == 63) wbase[wv] = incl;
     __syncthreads();
     int pos = incl - mine_n;
     for (int q = 0; q < wv; ++q) pos += wbase[q];
@@ -1051,13 +1128,14 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
                                                                 int32_t *__restrict__ diag,
                                                                 const int32_t *__restrict__ list,
                                                                 const uint64_t *__restrict__ pass,
-                                                                const int32_t *__restrict__ count)
+                                                                const int32_t *__restrict__ count,
+                                                                const uint16_t *__restrict__ cpop)
 {
     if ((int)blockIdx.x >= *count) return;                         // block-uniform
     long long t_start = 0;
     if (kDiag) t_start = (long long)__builtin_amdgcn_s_memrealtime();    // 100 MHz, one clock for the whole chip
     merge_tile_pair<kDiag>(list[blockIdx.x], pass[2 * blockIdx.x], pass[2 * blockIdx.x + 1], rows, n, nw, tmask, mw, hist,
-                           n_pos, row_sorted, area_sorted, label_sorted, thr, parent, n_tiles, diag);
+                           n_pos, row_sorted, area_sorted, label_sorted, thr, parent, n_tiles, diag, cpop);
     if (kDiag && threadIdx.x == 0 && diag[15] > 0 && (int)blockIdx.x < diag[15]) {
         // block timeline (diag[15] = capacity): start / end in 10-ns ticks (low 32 bits), at diag[16 + 2 b]
         diag[16 + 2 * blockIdx.x] = (int32_t)t_start;
@@ -1675,7 +1753,7 @@ extern "C" int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint6
 
 extern "C" int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *area, int32_t *mean_word,
                              uint64_t *chunk_mask, int32_t chunk_mask_given, uint32_t *hist, int64_t *signature,
-                             void *stream)
+                             uint16_t *chunk_pop, void *stream)
 {
     BFF_REQUIRE(n_rows >= 0 && nw >= 0, "bff_row_stats: bad sizes");
     if (n_rows == 0) return BFF_OK;
@@ -1685,12 +1763,16 @@ extern "C" int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, i
     const int mw = (int)ceil_div(n_chunks, 64);
     static_assert(kBins == kWave, "row_stats_sparse_kernel: one histogram bin per lane");
     if (chunk_mask_given) {
+        if (chunk_pop) {                            // the sparse pass writes the flagged chunks only
+            hipError_t e = hipMemsetAsync(chunk_pop, 0, sizeof(uint16_t) * (size_t)n_rows * mw * 64, as_stream(stream));
+            if (e != hipSuccess) return fail((int)e, "bff_row_stats: memset: %s", hipGetErrorString(e));
+        }
         row_stats_sparse_kernel<<<(unsigned)ceil_div(n_rows, 4), 256, 0, as_stream(stream)>>>(
-            rows, n_rows, nw, mw, (int)ceil_div(nw > 0 ? nw : 1, kBins), area, mean_word, chunk_mask, hist, signature);
+            rows, n_rows, nw, mw, (int)ceil_div(nw > 0 ? nw : 1, kBins), area, mean_word, chunk_mask, hist, signature, chunk_pop);
         return launched("bff_row_stats");
     }
     row_stats_kernel<<<n_rows, 256, mw * sizeof(uint64_t), as_stream(stream)>>>(
-        rows, nw, mw, (int)ceil_div(nw > 0 ? nw : 1, kBins), area, mean_word, chunk_mask, hist, signature);
+        rows, nw, mw, (int)ceil_div(nw > 0 ? nw : 1, kBins), area, mean_word, chunk_mask, hist, signature, chunk_pop);
     return launched("bff_row_stats");
 }
 
@@ -1756,7 +1838,7 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
                                     int32_t n_order, const uint64_t *chunk_mask, uint64_t *tile_mask,
                                     const uint32_t *hist, uint32_t *scratch, const int32_t *area,
                                     const int32_t *label_id, float iou_thres, int32_t *parent, int32_t init_parent,
-                                    int32_t *comp, int32_t *diag, void *stream)
+                                    int32_t *comp, int32_t *diag, const uint16_t *chunk_pop, void *stream)
 {
     BFF_REQUIRE(n_rows >= 0 && nw >= 0 && n_order >= 0 && n_order <= n_rows, "bff_merge_components: bad sizes");
     if (n_rows == 0) return BFF_OK;
@@ -1812,11 +1894,11 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
         if (diag)       // counters + phase clocks compiled in (a couple of registers more: one wave less per SIMD)
             hipExtLaunchKernelGGL(merge_components_kernel<true>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
                 rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
-                label_sorted, iou_thres, parent, nt, diag, list2, pass2, counts + 1);
+                label_sorted, iou_thres, parent, nt, diag, list2, pass2, counts + 1, chunk_pop);
         else
             hipExtLaunchKernelGGL(merge_components_kernel<false>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
                 rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
-                label_sorted, iou_thres, parent, nt, (int32_t *)nullptr, list2, pass2, counts + 1);
+                label_sorted, iou_thres, parent, nt, (int32_t *)nullptr, list2, pass2, counts + 1, chunk_pop);
     }
     if (comp) uf_flatten_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows, comp);
     return launched("bff_merge_components");

@@ -41,7 +41,7 @@ class ParamsStruct(ctypes.Structure):
 
 _WS_PTRS = ["maskbits", "segmap", "rows", "chunk_mask", "keep", "tile_mask", "agg", "both",
             "masked", "viewed", "sel_scratch", "area", "mean_word", "order", "parent", "comp", "count",
-            "gmembers", "goffs", "slices", "inter", "pair_masks", "pair_scratch", "vals", "vals_sorted", "hist", "merge_scratch",
+            "gmembers", "goffs", "slices", "inter", "pair_masks", "pair_scratch", "vals", "vals_sorted", "hist", "merge_scratch", "chunk_pop",
             "sig", "sig_keys", "sig_sorted", "sort_temp"]
 
 
@@ -182,6 +182,7 @@ class SceneWorkspace:
         self._need("vals", n, f32)
         self._need("vals_sorted", n, f32)
         self._need("hist", n_rows * 64, i32)
+        self._need("chunk_pop", n_rows * mw * 64, torch.int16)
         self._need("merge_scratch", int(lib.bff_merge_scratch_words(n_rows)), i32)
         for k in ("sig", "sig_keys", "sig_sorted"):
             self._need(k, n_rows, i64)

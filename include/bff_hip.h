@@ -154,9 +154,12 @@ int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t na,
  * first, unused slots = 63 (an empty row is all 63s and sorts last): rows showing the same object
  * get the same key, so sorting by it clusters them into the same 64-row tiles.
  * chunk_mask_given != 0: chunk_mask is an INPUT (as written by bff_project_views) and only the flagged chunks
- * of every row are read; 0: chunk_mask is computed here from a full pass over the rows. */
+ * of every row are read; 0: chunk_mask is computed here from a full pass over the rows.
+ * chunk_pop (optional, may be NULL): uint16 [n_rows][64 * bff_chunk_mask_words(nw)], points of the row in each of
+ * its 512-point chunks (0 where the row has none): the bins of bff_merge_components' second-level bound. */
 int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, int32_t *area, int32_t *mean_word,
-                  uint64_t *chunk_mask, int32_t chunk_mask_given, uint32_t *hist, int64_t *signature, void *stream);
+                  uint64_t *chunk_mask, int32_t chunk_mask_given, uint32_t *hist, int64_t *signature,
+                  uint16_t *chunk_pop, void *stream);
 int bff_chunk_mask_words(int64_t nw);
 
 /* rows[r][chunk c] = 0 for every chunk flagged in chunk_mask (as written by bff_project_views): returns a
@@ -206,6 +209,8 @@ int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const 
  * few chunks it settles the pairs whose PARTIAL intersection already passes the IoU test (the float32 expression is
  * monotone in I, so the edge exists) or whose rows have become connected meanwhile, and stops as soon as no pair is
  * open; only edges that merge two local sets are pushed into `parent`.
+ * chunk_pop (optional, from bff_row_stats): second-level bound -- pairs that pass the 64-bin histogram bound are
+ * bounded again by sum over the shared 512-point chunks of min(points of i, points of j) before any word is read.
  * diag (optional, NULL in production): int32 [16 + 2 * capacity], zeroed by the caller: += {tile pairs evaluated,
  * chunks visited, candidate pairs, unions, phase clocks ...} (scripts/diag_merge_phases.py). */
 int64_t bff_merge_scratch_words(int32_t n_rows);
@@ -215,7 +220,8 @@ int bff_profile_next_merge(void *start_event, void *stop_event);
 int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order, int32_t n_order,
                          const uint64_t *chunk_mask, uint64_t *tile_mask, const uint32_t *hist,
                          uint32_t *scratch, const int32_t *area, const int32_t *label_id, float iou_thres,
-                         int32_t *parent, int32_t init_parent, int32_t *comp, int32_t *diag, void *stream);
+                         int32_t *parent, int32_t init_parent, int32_t *comp, int32_t *diag,
+                         const uint16_t *chunk_pop, void *stream);
 
 /* rows_out[r] bit o = rows_in[r] bit idx[o], o < n_out (bit gather).  Undoes the spatial point sort the
  * host applies at upload: idx[o] = position of original point o in the sorted cloud. */
@@ -460,6 +466,7 @@ typedef struct bff_scene_workspace {
     uint32_t *pair_scratch;         /* bff_point_threshold_scratch_words() */
     float *vals, *vals_sorted;
     uint32_t *hist, *merge_scratch;
+    uint16_t *chunk_pop;            /* [n_rows][64 * chunk-mask words] */
     int64_t *sig, *sig_keys, *sig_sorted;
     void *sort_temp; size_t sort_temp_bytes;
     size_t zero_bytes;              /* size of the block masked | viewed | count | chunk_mask */
