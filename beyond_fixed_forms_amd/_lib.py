@@ -69,7 +69,7 @@ SIGNATURES = {
 }
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
          "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
-         "bff_point_tile_size": (c_int32, []), "bff_merge_scratch_words": (c_int64, [c_int32]),
+         "bff_point_tile_size": (c_int32, []), "bff_merge_scratch_words": (c_int64, [c_int32]), "bff_merge_uses_chunk_bound": (c_int32, [c_int64]),
          "bff_profile_next_merge": (c_int32, [_P, _P]), "bff_group_slice_cap": (c_int32, [c_int32, c_int32]),
          "bff_resolve_overlaps_scratch_words": (c_int64, []), "bff_point_threshold_scratch_words": (c_int64, []), "bff_scene_header_words": (c_int32, [c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
@@ -530,7 +530,7 @@ def point_threshold(masked, viewed, fraction):
 def point_threshold_pairs(masked, viewed, fraction):
     """point_threshold without sorting: the statistic is a function of the integer pair (masked, viewed); mark the
     pairs that occur, hash their float32 values into a set, radix-select the rank.  Returns (thr f32[1], n_unique
-    i32[1], overflow i32[1]) on the device; overflow != 0: more distinct values than the set holds, use
+    i32[1], overflow i32[1]) on the device; overflow != 0: more distinct values than the set holds (2^17), use
     point_threshold."""
     n = masked.shape[0]
     dev = masked.device

@@ -83,6 +83,11 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_strip_kernel(const _Float
     if (tid < kStrip) s_nb[tid] = 0.f;
     for (int kc = 0; kc < dim; kc += kStripK) {                    // dims beyond 768: the strip is staged in pieces
         const int kn = min(kStripK, dim - kc), segs = kn / 8;      // 16-byte segments per row
+        // the wave's own A fragments of this piece: all loads issued before anything waits (a wave alone on its SIMD
+        // has nobody to hide a load behind)
+        half8 fa[kStripK / 32];
+#pragma unroll
+        for (int q = 0; q < kStripK / 32; ++q) fa[q] = (ra && 32 * q < kn) ? *reinterpret_cast<const half8 *>(pa + kc + 32 * q) : zero;
         __syncthreads();                                           // previous piece fully consumed / s_nb zeroed
         for (int sidx = tid; sidx < kStrip * segs; sidx += 256) {
             const int row = sidx / segs, seg = sidx - row * segs;
@@ -99,14 +104,16 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_strip_kernel(const _Float
                 for (int d = 32; d > 0; d >>= 1) q += __shfl_xor(q, d);
                 if (lane == 0) s_nb[row] += q;
             }
-        for (int k0 = 0; k0 < kn; k0 += 32) {
-            const half8 fa = ra ? *reinterpret_cast<const half8 *>(pa + kc + k0) : zero;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sa = fmaf((float)fa[e], (float)fa[e], sa);
+        for (int q = 0; q < kStripK / 32; ++q) {
+            if (32 * q < kn) {                                     // block-uniform
 #pragma unroll
-            for (int t = 0; t < kStripTiles; ++t) {
-                const half8 fb = *reinterpret_cast<const half8 *>(sb + (size_t)(t * 16 + r) * kStripPitch + k0 + 8 * kq);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc[t], 0, 0, 0);
+                for (int e = 0; e < 8; ++e) sa = fmaf((float)fa[q][e], (float)fa[q][e], sa);
+#pragma unroll
+                for (int t = 0; t < kStripTiles; ++t) {
+                    const half8 fb = *reinterpret_cast<const half8 *>(sb + (size_t)(t * 16 + r) * kStripPitch + 32 * q + 8 * kq);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[q], fb, acc[t], 0, 0, 0);
+                }
             }
         }
     }

@@ -92,64 +92,66 @@ __global__ __launch_bounds__(1024) void distinct_select_kernel(const float *__re
 // ---- the same threshold without sorting N values --------------------------------------------------------
 // The filter statistic of a point is a function of two small integers, (masked, viewed): float32(masked) /
 // (float32(viewed) + 1) (or float32(masked) alone).  A scene has ~10^5..10^6 points but only ~10^3..10^4 distinct
-// pairs, so: (1) mark the pairs that occur in a bitmap (pairs outside its range go straight to step 2's table),
-// (2) turn every present pair into its float32 value and insert it into a hash set of bit patterns -- the set of
-// distinct VALUES is exactly x.unique() of the reference (different pairs may give the same quotient), (3) select
-// the value of rank floor(frac * n_distinct) among them with a 4-pass byte-wise radix select (values are >= 0, so
-// the order of the bit patterns is the order of the values).  Three small launches instead of a 9-launch radix
-// sort of N floats; bit-identical threshold.
-constexpr int kPairM = 4096, kPairV = 1024;                  // bitmap range: masked < 4096, viewed < 1024
-constexpr int kPairWords = kPairM * kPairV / 32;              // 128 Ki words = 512 KiB
-constexpr uint32_t kHashSlots = 1u << 18;                     // distinct values the set can hold (256 Ki)
-constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;                  // not a value: NaN pattern (the statistic is never NaN)
+// values, so: (1) every block of 1024 points collects the distinct values of ITS points in an LDS hash set (most
+// points repeat a value -- half of them are 0 -- and LDS reads are coherent, so a repeated value costs one probe),
+// then adds them to a global hash set of bit patterns with compare-and-swap: the set of distinct values is exactly
+// x.unique() of the reference; (2) one block selects the value of rank floor(frac * n_distinct) among them with a
+// 4-pass byte-wise radix select (values are >= 0, so the order of the bit patterns is the order of the values).
+// Two small launches instead of a 9-launch radix sort of N floats; bit-identical threshold.
+constexpr uint32_t kHashSlots = 1u << 18;                     // slots of the global set: it holds 2^17 distinct values
+constexpr uint32_t kLocalSlots = 2048;                        // LDS set of one block (1024 points -> <= 1024 values)
+constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;                  // not a value: a NaN pattern (the statistic is never NaN)
 
 __device__ __forceinline__ float pair_value(int m, int v, bool ratio)
 {
     return ratio ? __fdiv_rn((float)m, __fadd_rn((float)v, 1.0f)) : (float)m;
 }
 
-// returns false when the table is full
+// returns false when the set is full: it holds kHashSlots / 2 values (load factor 1/2 keeps the probe sequences short)
 __device__ __forceinline__ bool hash_insert(uint32_t *__restrict__ table, uint32_t *__restrict__ list,
                                             uint32_t *__restrict__ count, uint32_t bits)
 {
     uint32_t h = (bits * 2654435761u) >> (32 - 18);
-    for (uint32_t probe = 0; probe < kHashSlots; ++probe) {
-        const uint32_t old = atomicCAS(table + h, kHashEmpty, bits);
-        if (old == kHashEmpty) { list[atomicAdd(count, 1u)] = bits; return true; }
+    for (uint32_t probe = 0; probe < 4096; ++probe) {
+        uint32_t old = __hip_atomic_load(table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not a stale L1 line
+        if (old == kHashEmpty) {
+            if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kHashSlots / 2) return false;
+            old = atomicCAS(table + h, kHashEmpty, bits);
+        }
+        if (old == kHashEmpty) {
+            const uint32_t at = atomicAdd(count, 1u);
+            if (at < kHashSlots) list[at] = bits;
+            return at < kHashSlots / 2;
+        }
         if (old == bits) return true;
         h = (h + 1) & (kHashSlots - 1);
     }
     return false;
 }
 
-__global__ void pair_mark_kernel(const int32_t *__restrict__ masked, const int32_t *__restrict__ viewed, int64_t n,
-                                 uint32_t *__restrict__ bitmap, uint32_t *__restrict__ table, uint32_t *__restrict__ list,
-                                 uint32_t *__restrict__ count, int32_t *__restrict__ overflow)
+__global__ __launch_bounds__(1024) void value_set_kernel(const int32_t *__restrict__ masked, const int32_t *__restrict__ viewed,
+                                                          int64_t n, uint32_t *__restrict__ table, uint32_t *__restrict__ list,
+                                                          uint32_t *__restrict__ count, int32_t *__restrict__ overflow)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int m = masked[i], v = viewed ? viewed[i] : 0;
-    if (m >= 0 && m < kPairM && v >= 0 && v < kPairV) {
-        const uint32_t bit = (uint32_t)m * kPairV + (uint32_t)v;
-        const uint32_t w = bitmap[bit >> 5];                  // most points repeat a pair: test before the atomic
-        if (!((w >> (bit & 31)) & 1)) atomicOr(bitmap + (bit >> 5), 1u << (bit & 31));
-    } else if (!hash_insert(table, list, count, __float_as_uint(pair_value(m, v, viewed != nullptr)))) {
-        *overflow = 1;
+    __shared__ uint32_t local[kLocalSlots];
+    const int tid = threadIdx.x;
+    for (int q = tid; q < (int)kLocalSlots; q += 1024) local[q] = kHashEmpty;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+    if (i < n) {
+        const uint32_t bits = __float_as_uint(pair_value(masked[i], viewed ? viewed[i] : 0, viewed != nullptr));
+        uint32_t h = (bits * 2654435761u) >> (32 - 11);
+        for (;;) {                                             // <= 1024 values in 2048 slots: always terminates
+            uint32_t old = local[h];
+            if (old == kHashEmpty) old = atomicCAS(&local[h], kHashEmpty, bits);
+            if (old == kHashEmpty || old == bits) break;
+            h = (h + 1) & (kLocalSlots - 1);
+        }
     }
-}
-
-__global__ void pair_values_kernel(const uint32_t *__restrict__ bitmap, int ratio, uint32_t *__restrict__ table,
-                                   uint32_t *__restrict__ list, uint32_t *__restrict__ count, int32_t *__restrict__ overflow)
-{
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= kPairWords) return;
-    uint32_t bits = bitmap[w];
-    while (bits) {
-        const int b = __ffs(bits) - 1;
-        bits &= bits - 1;
-        const uint32_t pair = (uint32_t)w * 32 + b;
-        const float f = pair_value((int)(pair / kPairV), (int)(pair % kPairV), ratio != 0);
-        if (!hash_insert(table, list, count, __float_as_uint(f))) *overflow = 1;
+    __syncthreads();
+    for (int q = tid; q < (int)kLocalSlots; q += 1024) {
+        const uint32_t bits = local[q];
+        if (bits != kHashEmpty && !hash_insert(table, list, count, bits)) *overflow = 1;
     }
 }
 
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(1024) void pair_select_kernel(const uint32_t *__res
 {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_prefix, s_rank;
-    const uint32_t n = *count;
+    const uint32_t n = min(*count, kHashSlots);
     const int tid = threadIdx.x;
     if (tid == 0) {
         *n_unique = (int32_t)n;
@@ -297,26 +299,24 @@ extern "C" int bff_depth_from_u16(const uint16_t *src, int32_t n_frames, int32_t
     return launched("bff_depth_from_u16");
 }
 
-extern "C" int64_t bff_point_threshold_scratch_words(void) { return (int64_t)kPairWords + 2 * (int64_t)kHashSlots + 4; }
+extern "C" int64_t bff_point_threshold_scratch_words(void) { return 2 * (int64_t)kHashSlots + 4; }
 
-// thr / n_unique as bff_point_values + bff_sort_f32 + bff_select_unique_rank deliver them, from the pairs that
-// occur.  scratch: uint32 [bff_point_threshold_scratch_words()].  *overflow (device int32, NOT cleared here) is set
-// to 1 when the scene has more distinct values than the set holds (2^18): thr is then undefined and the caller must
-// take the sorting path.
+// thr / n_unique as bff_point_values + bff_sort_f32 + bff_select_unique_rank deliver them, from the distinct values
+// that occur.  scratch: uint32 [bff_point_threshold_scratch_words()].  *overflow (device int32, NOT cleared here) is
+// set to 1 when the scene has more distinct values than the set holds (2^17): thr is then undefined and the caller
+// must take the sorting path.
 extern "C" int bff_point_threshold_pairs(const int32_t *masked, const int32_t *viewed, int64_t n_points, double fraction,
                                          uint32_t *scratch, float *thr, int32_t *n_unique, int32_t *overflow, void *stream)
 {
     BFF_REQUIRE(n_points >= 0 && scratch && thr && n_unique && overflow, "bff_point_threshold_pairs: bad arguments");
     hipStream_t st = as_stream(stream);
-    uint32_t *bitmap = scratch, *table = bitmap + kPairWords, *list = table + kHashSlots, *count = list + kHashSlots;
-    hipError_t e = hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * kPairWords, st);
-    if (e == hipSuccess) e = hipMemsetAsync(table, 0xFF, sizeof(uint32_t) * kHashSlots, st);
+    uint32_t *table = scratch, *list = table + kHashSlots, *count = list + kHashSlots;
+    hipError_t e = hipMemsetAsync(table, 0xFF, sizeof(uint32_t) * kHashSlots, st);
     if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(uint32_t) * 4, st);
     if (e != hipSuccess) return fail((int)e, "bff_point_threshold_pairs: memset: %s", hipGetErrorString(e));
     if (n_points > 0) {
         BFF_REQUIRE(masked, "bff_point_threshold_pairs: null pointer");
-        pair_mark_kernel<<<(unsigned)ceil_div(n_points, 256), 256, 0, st>>>(masked, viewed, n_points, bitmap, table, list, count, overflow);
-        pair_values_kernel<<<kPairWords / 256, 256, 0, st>>>(bitmap, viewed ? 1 : 0, table, list, count, overflow);
+        value_set_kernel<<<(unsigned)ceil_div(n_points, 1024), 1024, 0, st>>>(masked, viewed, n_points, table, list, count, overflow);
     }
     pair_select_kernel<<<1, 1024, 0, st>>>(list, count, fraction, thr, n_unique);
     return launched("bff_point_threshold_pairs");

@@ -1826,6 +1826,17 @@ extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t
     return launched("bff_merge_adjacency");
 }
 
+// The second-level (chunk) bound pays when a histogram bin is much coarser than a chunk -- clouds of ~0.5 M points and
+// more (config 4: tile pass 8.4 -> 2.7 ms); on smaller clouds the pairs that survive the 64-bin bound are genuine
+// near-misses that the chunk bound cannot reject either, and its table look-ups cost more than they save (config 2:
+// 0.45 -> 0.52 ms).  BFF_CHUNK_BOUND=0/1 forces it off / on.
+extern "C" int32_t bff_merge_uses_chunk_bound(int64_t nw)
+{
+    static const int forced = [] { const char *e = getenv("BFF_CHUNK_BOUND"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced != 0;
+    return ceil_div(nw > 0 ? nw : 1, kBins) >= 16 * kCW;
+}
+
 extern "C" int64_t bff_merge_scratch_words(int32_t n_rows)
 {
     const int64_t nt = ceil_div(n_rows > 0 ? n_rows : 1, kT), n_pos = nt * kT, total = nt * (nt + 1) / 2;
@@ -1850,6 +1861,7 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
     BFF_LIMIT(n_chunks <= kMaxChunks, "bff_merge_components: more than %d chunks (N > %d points)", kMaxChunks, kMaxChunks * kCW * 64);
     const int mw = (int)ceil_div(n_chunks, 64);
     hipStream_t st = as_stream(stream);
+    if (chunk_pop && !bff_merge_uses_chunk_bound(nw)) chunk_pop = nullptr;
     if (init_parent) uf_init_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows);
     if (n_order > 0) {
         // an empty intersection gives IoU 0 (or NaN): such pairs can only be skipped when 0 > thr is false

@@ -92,8 +92,8 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
         BFF_TRY(bff_ratio_keep(ws->masked, nullptr, n, 0.0f, nullptr, 0, nw, ws->keep, stream));
     }
     // a9-a12: statistics through the chunk flags, tile order (label, signature), components
-    BFF_TRY(bff_row_stats(ws->rows, n_rows, nw, ws->area, ws->mean_word, ws->chunk_mask, 1, ws->hist, ws->sig, ws->chunk_pop,
-                          stream));
+    uint16_t *cpop = bff_merge_uses_chunk_bound(nw) ? ws->chunk_pop : nullptr;
+    BFF_TRY(bff_row_stats(ws->rows, n_rows, nw, ws->area, ws->mean_word, ws->chunk_mask, 1, ws->hist, ws->sig, cpop, stream));
     {
         const int64_t *keys = ws->sig;
         int key_bits = BFF_SIGNATURE_BITS;
@@ -108,7 +108,7 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     }
     BFF_TRY(bff_merge_components(ws->rows, n_rows, nw, ws->order, n_rows, ws->chunk_mask, ws->tile_mask, ws->hist,
                                  ws->merge_scratch, ws->area, sc->label_id, pr->iou_thres, ws->parent, 1, ws->comp, nullptr,
-                                 ws->chunk_pop, stream));
+                                 cpop, stream));
     // P:203-226 on the device: groups, OR of the members, sequential confidence means
     int32_t *info = hdr + BFF_HDR_K;
     BFF_TRY(bff_group_components(ws->comp, ws->area, n_rows, pr->iou_thres, pr->min_members, cap, ws->count, 1, info,

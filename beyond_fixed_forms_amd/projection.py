@@ -512,7 +512,11 @@ def _projection_back(fr: _Front, timers, phases, stage1=None) -> Stage2Result:
 def project_scene(scene, cfg, device="cuda", return_result: bool = False, debug_out: bool = False):
     """Reference-shaped entry point: in-memory scene inputs -> the dict saved at P:630-634."""
     _lib.load()                                     # fail loudly before any work if the library is missing
-    ds = prepare_scene(scene, cfg, device=device,
-                       with_viewed=(not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold))
+    with_viewed = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
+    if torch.device(device).type == "cuda" and not debug_out:
+        from .ingest import prepare_scene_fast      # native run tables, packed pinned uploads, cloud laid out on the device
+        ds = prepare_scene_fast(scene, cfg, device=device, with_viewed=with_viewed)
+    else:
+        ds = prepare_scene(scene, cfg, device=device, with_viewed=with_viewed)
     res = run_projection(ds, cfg, debug_out=debug_out)
     return res if return_result else res.to_dict()

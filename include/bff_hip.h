@@ -214,6 +214,9 @@ int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t nw, const 
  * diag (optional, NULL in production): int32 [16 + 2 * capacity], zeroed by the caller: += {tile pairs evaluated,
  * chunks visited, candidate pairs, unions, phase clocks ...} (scripts/diag_merge_phases.py). */
 int64_t bff_merge_scratch_words(int32_t n_rows);
+/* Whether bff_merge_components applies the chunk bound for rows of nw words (clouds of >= ~0.5 M points; the environment
+ * variable BFF_CHUNK_BOUND=0/1 overrides): callers can skip computing chunk_pop otherwise. */
+int32_t bff_merge_uses_chunk_bound(int64_t nw);
 /* Profiling aid: the next tile-pass dispatch of bff_merge_components on this host thread carries the two events
  * (like bff_profile_next_sweep). */
 int bff_profile_next_merge(void *start_event, void *stop_event);
@@ -325,9 +328,10 @@ int bff_ids_to_rows(const int64_t *ids, int64_t n_points, const int64_t *values,
  * masked > 0. */
 int bff_point_values(const int32_t *masked, const int32_t *viewed, int64_t n_points, float *vals, void *stream);
 /* The same (thr, n_unique) without sorting n_points values: the statistic is a function of the integer pair (masked,
- * viewed), of which a scene holds only ~10^3..10^4 different ones: mark the pairs, hash their float32 values into a set
- * (= x.unique() of P:516 / P:574), radix-select the rank.  scratch: uint32 [bff_point_threshold_scratch_words()];
- * *overflow (device, not cleared by the call) is set to 1 if the set (2^18 values) is full: use the sorting path then. */
+ * viewed), of which a scene holds only ~10^3..10^4 different ones: every block collects the distinct values of its
+ * points in LDS, the blocks' sets meet in a global hash set (= x.unique() of P:516 / P:574), one block radix-selects the
+ * rank.  scratch: uint32 [bff_point_threshold_scratch_words()]; *overflow (device, not cleared by the call) is set to 1
+ * if the set (2^17 values) is full: use the sorting path then. */
 int64_t bff_point_threshold_scratch_words(void);
 int bff_point_threshold_pairs(const int32_t *masked, const int32_t *viewed, int64_t n_points, double fraction,
                               uint32_t *scratch, float *thr, int32_t *n_unique, int32_t *overflow, void *stream);

@@ -175,6 +175,14 @@ def test_disk_round_trip_and_cli_paths(tmp_path):
     assert up.shape == (2 * sc.height, 2 * sc.width) and up.dtype == np.float32
     assert abs(float(up.mean()) - float(sc.depths["0"].mean())) < 0.02
     assert io.scene_checkpoint_file("refinement", "table") == "checkpoints/refinement_checkpoint_table.yaml"
+    # the pose / intrinsic reader == np.loadtxt on the files np.savetxt wrote (and on hand-written ScanNet-style text)
+    for fid in list(sc.poses)[:3]:
+        pth = sd / "pose" / f"{fid}.txt"
+        assert np.array_equal(io.read_matrix_txt(str(pth)), np.loadtxt(pth))
+    hand = tmp_path / "hand.txt"
+    hand.write_text("1170.187988 0.000000 647.750000 0.000000\n0.000000 1170.187988 483.750000 0.000000\n"
+                    "0 0 1 0\n-1.5e-3 2E+1 0.1 1\n")
+    assert np.array_equal(io.read_matrix_txt(str(hand)), np.loadtxt(hand))
 
 
 def test_sim_threshold_semantics():
