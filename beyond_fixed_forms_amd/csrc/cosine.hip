@@ -54,85 +54,6 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_kernel(const _Float16 *__
 }
 
 
-// The same product for MANY rows against a bank of <= a few hundred columns (BASELINE config 5: 9000 x 768 features
-// x 200 labels; the box filter of segmentation_2d.py:388-393 batched over all frames and queries): a block of 4 waves
-// owns 64 feature rows and a strip of kStrip = 96 bank columns that it stages ONCE, whole (<= 768 k), in LDS -- every
-// load of the strip is in flight at the same time (147 KB behind one barrier instead of 24 dependent L2 round
-// trips) -- and each wave then runs 6 MFMAs per 32-deep k-step out of LDS against its own A fragments, which come
-// straight from global memory (one 16-byte load per lane and step, read exactly once).  Row pitch 392 dwords: the
-// sixteen 16-byte fragment reads of a ds_read_b128 lane group start at distinct multiples of 4 banks.
-constexpr int kStripTiles = 6, kStrip = kStripTiles * 16, kStripK = 768, kStripPitch = kStripK + 16;   // halfs
-
-__global__ __launch_bounds__(256) void cosine_gemm_f16_strip_kernel(const _Float16 *__restrict__ a, int na,
-                                                                     const _Float16 *__restrict__ b, int nb, int dim,
-                                                                     float *__restrict__ out, int norm_b)
-{
-    extern __shared__ _Float16 s_dyn[];
-    _Float16 *sb = s_dyn;                                          // [kStrip][kStripPitch]
-    float *s_nb = reinterpret_cast<float *>(s_dyn + (size_t)kStrip * kStripPitch);     // [kStrip] sum of squares
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = (blockIdx.x * 4 + wave) * 16, j0 = blockIdx.y * kStrip;
-    const int r = lane & 15, kq = lane >> 4;
-    const bool ra = i0 + r < na;
-    const _Float16 *pa = a + (int64_t)(ra ? i0 + r : 0) * dim + 8 * kq;
-    float4v acc[kStripTiles];
-#pragma unroll
-    for (int t = 0; t < kStripTiles; ++t) acc[t] = (float4v){0.f, 0.f, 0.f, 0.f};
-    float sa = 0.f;
-    const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (tid < kStrip) s_nb[tid] = 0.f;
-    for (int kc = 0; kc < dim; kc += kStripK) {                    // dims beyond 768: the strip is staged in pieces
-        const int kn = min(kStripK, dim - kc), segs = kn / 8;      // 16-byte segments per row
-        // the wave's own A fragments of this piece: all loads issued before anything waits (a wave alone on its SIMD
-        // has nobody to hide a load behind)
-        half8 fa[kStripK / 32];
-#pragma unroll
-        for (int q = 0; q < kStripK / 32; ++q) fa[q] = (ra && 32 * q < kn) ? *reinterpret_cast<const half8 *>(pa + kc + 32 * q) : zero;
-        __syncthreads();                                           // previous piece fully consumed / s_nb zeroed
-        for (int sidx = tid; sidx < kStrip * segs; sidx += 256) {
-            const int row = sidx / segs, seg = sidx - row * segs;
-            half8 v = zero;
-            if (j0 + row < nb) v = *reinterpret_cast<const half8 *>(b + (int64_t)(j0 + row) * dim + kc + 8 * seg);
-            *reinterpret_cast<half8 *>(sb + (size_t)row * kStripPitch + 8 * seg) = v;
-        }
-        __syncthreads();
-        if (norm_b)                                                // squared norms of the staged piece: wave w takes rows w, w + 4, ...
-            for (int row = wave; row < kStrip; row += 4) {
-                float q = 0.f;
-                for (int k = lane; k < kn; k += 64) { const float x = (float)sb[(size_t)row * kStripPitch + k]; q = fmaf(x, x, q); }
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) q += __shfl_xor(q, d);
-                if (lane == 0) s_nb[row] += q;
-            }
-#pragma unroll
-        for (int q = 0; q < kStripK / 32; ++q) {
-            if (32 * q < kn) {                                     // block-uniform
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sa = fmaf((float)fa[q][e], (float)fa[q][e], sa);
-#pragma unroll
-                for (int t = 0; t < kStripTiles; ++t) {
-                    const half8 fb = *reinterpret_cast<const half8 *>(sb + (size_t)(t * 16 + r) * kStripPitch + 32 * q + 8 * kq);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[q], fb, acc[t], 0, 0, 0);
-                }
-            }
-        }
-    }
-    __syncthreads();                                               // the bank norms of the last piece, written by other waves
-    sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);           // the four k-quarters of a row: lanes r, r+16, r+32, r+48
-#pragma unroll
-    for (int t = 0; t < kStripTiles; ++t) {
-        const int j = j0 + t * 16 + r;                            // C/D map: col = lane & 15, row = 4 * (lane >> 4) + q
-        const float nbj = norm_b ? sqrtf(s_nb[t * 16 + r]) : 1.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = kq * 4 + q;
-            const float nai = sqrtf(__shfl(sa, row));
-            const int i = i0 + row;
-            if (i < na && j < nb) out[(int64_t)i * nb + j] = acc[t][q] / (nai * nbj);
-        }
-    }
-}
-
 // Cosine of every (a_i, b_j) pair IN THE DTYPE OF THE EMBEDDINGS, i.e. with the roundings of the reference's
 // tensor expression  (e1 @ e2.T) / (e1.norm() * e2.norm().T)  (compute_clip_similarity R:109-114): each of the
 // four tensor ops rounds its result to the embedding dtype.  The class threshold of the refinement is an order
@@ -182,20 +103,6 @@ static int launch_cosine_gemm(const void *a, int32_t na, const void *b, int32_t 
     BFF_REQUIRE(dim % 32 == 0, "%s: dim must be a multiple of 32", what);
     if (na == 0 || nb == 0) return BFF_OK;
     BFF_REQUIRE(a && b && cos, "%s: null pointer", what);
-    if (na >= 64) {                                               // many rows: bank strips staged whole in LDS
-        static bool attr_set = false;
-        const size_t lds = sizeof(_Float16) * (size_t)kStrip * kStripPitch + sizeof(float) * kStrip;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_gemm_f16_strip_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return fail((int)e, "%s: LDS attribute: %s", what, hipGetErrorString(e));
-            attr_set = true;
-        }
-        dim3 grid((unsigned)ceil_div(na, 64), (unsigned)ceil_div(nb, kStrip));
-        cosine_gemm_f16_strip_kernel<<<grid, 256, lds, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b, nb,
-                                                                           dim, cos, norm_b);
-        return launched(what);
-    }
     dim3 grid((unsigned)ceil_div(ceil_div(nb, 16), 4), (unsigned)ceil_div(na, 16));
     cosine_gemm_f16_kernel<<<grid, 256, 0, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b, nb, dim, cos, norm_b);
     return launched(what);

@@ -542,3 +542,22 @@ def test_overlapped_ingestion_equals_prepare_scene(api):
             exp = pref.project_scene_ref(sc, cfg)
         same(res.to_dict(), exp)
     ing.close()
+
+
+def test_value_set_threshold_in_the_scene_call(api, monkeypatch):
+    """BFF_FILTER_SET=1: bff_scene_project takes the point-filter threshold from the set of distinct values
+    (bff_point_threshold_pairs) instead of sorting all values -- same threshold bits, same results."""
+    projection, _ = api
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    from beyond_fixed_forms_amd.synthetic import make_scene
+    for mode_over in ({}, dict(if_occurance_threshold=True)):
+        scene = make_scene("tiny", seed=71)
+        cfg = cfg_for(scene, **mode_over)
+        ds = prepare_scene(scene, cfg, device=DEV)
+        monkeypatch.delenv("BFF_FILTER_SET", raising=False)
+        a = projection.run_projection(ds, cfg)
+        monkeypatch.setenv("BFF_FILTER_SET", "1")
+        b = projection.run_projection(ds, cfg)
+        assert a.debug["path"] == b.debug["path"] == "fast"
+        assert np.float32(a.debug["thr"]).tobytes() == np.float32(b.debug["thr"]).tobytes()
+        assert torch.equal(a.rows, b.rows) and torch.equal(a.conf, b.conf) and list(a.groups) == list(b.groups)
