@@ -684,7 +684,7 @@ __global__ __launch_bounds__(256) void tile_pair_rows_kernel(const uint32_t *__r
     const int aA = area_sorted[bi * kT + lane], aB = area_sorted[bj * kT + lane];
     const int aminA = tile_amin[bi], aminB = tile_amin[bj];
     uint32_t uA = 0, uB = 0;
-#pragma unroll 8
+#pragma unroll                                    // fully: the broadcasts below become v_readlane with constant lanes
     for (int b = 0; b < kBP; ++b) {
         const uint32_t wa = hist[(int64_t)b * n_pos + bi * kT + lane];
         const uint32_t wb = hist[(int64_t)b * n_pos + bj * kT + lane];
@@ -1307,8 +1307,8 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restr
     // slice s of group g covers members [offs[g] + 32 j, min(offs[g+1], ...)): table rows (group, lo, hi)
     const int n_slices = min(s_soff[k], slice_cap);
     for (int sidx = tid; sidx < n_slices; sidx += 1024) {
-        int g = 0;
-        while (g + 1 < k && s_soff[g + 1] <= sidx) ++g;
+        int g = 0, hi = k - 1;                       // last group whose first slice is <= sidx
+        while (g < hi) { const int mid = (g + hi + 1) >> 1; if (s_soff[mid] <= sidx) g = mid; else hi = mid - 1; }
         const int lo = s_off[g] + (sidx - s_soff[g]) * kOrSplit;
         slices[sidx] = g;
         slices[slice_cap + sidx] = lo;
@@ -1507,17 +1507,41 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
 #pragma unroll 8
     for (int r = 0; r < k; ++r) s_col[r * kPitch + t] = w < nw ? rows[(int64_t)r * nw + w] : 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // single wave: its LDS ops complete in order
-    for (int i = 0; i < k; ++i)
+    // The reference's ordered pair loop (P:285-299) for this thread's word column.  Row i stays in a register while its
+    // partners j > i are visited; their words are read eight at a time (independent LDS reads, one latency per batch
+    // instead of one read-modify-write round trip per pair), updated in registers in the reference's order, and the
+    // ones that changed are written back.
+    for (int i = 0; i < k; ++i) {
+        uint64_t acc = s_col[i * kPitch + t];
+        const int size_i = s_size[i];
+        bool touched = false;
         for (int q = 0; q < kw; ++q) {
             unsigned long long m = s_mask[i * kMW + q];       // wave-uniform
             while (m) {
-                const int j = 64 * q + __ffsll(m) - 1;
-                m &= m - 1;
-                const bool i_wins = s_size[i] > s_size[j];    // ties: i loses (P:296-299)
-                const int d = i_wins ? j : i, sr = i_wins ? i : j;
-                s_col[d * kPitch + t] &= ~s_col[sr * kPitch + t];
+                int js[8];
+                uint64_t v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    js[e] = -1;
+                    if (m) { js[e] = 64 * q + __ffsll(m) - 1; m &= m - 1; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = js[e] >= 0 ? s_col[js[e] * kPitch + t] : 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (js[e] >= 0) {                          // wave-uniform
+                        if (size_i > s_size[js[e]]) {          // i wins: j loses the current overlap (ties: i loses, P:296-299)
+                            v[e] &= ~acc;
+                            s_col[js[e] * kPitch + t] = v[e];
+                        } else {
+                            acc &= ~v[e];
+                            touched = true;
+                        }
+                    }
             }
         }
+        if (touched) s_col[i * kPitch + t] = acc;
+    }
     const uint64_t kp = keep ? (w < nw ? keep[w] : 0) : ~0ull;
     for (int r = 0; r < k; ++r) {
         const uint64_t v = s_col[r * kPitch + t] & kp;
