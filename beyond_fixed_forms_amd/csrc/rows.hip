@@ -1116,8 +1116,9 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
 
 // Tile pass over the filtered list: block b takes entry b; blocks beyond the list (its length is only known on
 // the device) leave at once.  (A grid-stride or work-queue loop around the tile pair costs 60-80 registers and a
-// third of the occupancy: measured slower.)
-template <bool kDiag>
+// third of the occupancy: measured slower.)  kMode: 0 production; 1 counters + phase clocks (costs registers: one
+// block less per CU); 2 block timeline only -- start / end of every block at production occupancy.
+template <int kMode>
 __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
                                                                 const uint64_t *__restrict__ tmask, int mw,
                                                                 const uint32_t *__restrict__ hist, int n_pos,
@@ -1133,10 +1134,10 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
 {
     if ((int)blockIdx.x >= *count) return;                         // block-uniform
     long long t_start = 0;
-    if (kDiag) t_start = (long long)__builtin_amdgcn_s_memrealtime();    // 100 MHz, one clock for the whole chip
-    merge_tile_pair<kDiag>(list[blockIdx.x], pass[2 * blockIdx.x], pass[2 * blockIdx.x + 1], rows, n, nw, tmask, mw, hist,
-                           n_pos, row_sorted, area_sorted, label_sorted, thr, parent, n_tiles, diag, cpop);
-    if (kDiag && threadIdx.x == 0 && diag[15] > 0 && (int)blockIdx.x < diag[15]) {
+    if (kMode) t_start = (long long)__builtin_amdgcn_s_memrealtime();    // 100 MHz, one clock for the whole chip
+    merge_tile_pair<kMode == 1>(list[blockIdx.x], pass[2 * blockIdx.x], pass[2 * blockIdx.x + 1], rows, n, nw, tmask, mw, hist,
+                                n_pos, row_sorted, area_sorted, label_sorted, thr, parent, n_tiles, kMode == 1 ? diag : nullptr, cpop);
+    if (kMode && threadIdx.x == 0 && diag[15] > 0 && (int)blockIdx.x < diag[15]) {
         // block timeline (diag[15] = capacity): start / end in 10-ns ticks (low 32 bits), at diag[16 + 2 b]
         diag[16 + 2 * blockIdx.x] = (int32_t)t_start;
         diag[17 + 2 * blockIdx.x] = (int32_t)(long long)__builtin_amdgcn_s_memrealtime();
@@ -1927,12 +1928,17 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
                                                                            list2, pass2, counts + 1);
         const hipEvent_t ev0 = g_merge_start, ev1 = g_merge_stop;      // attached to the dispatch itself when set
         g_merge_start = g_merge_stop = nullptr;
-        if (diag)       // counters + phase clocks compiled in (a couple of registers more: one wave less per SIMD)
-            hipExtLaunchKernelGGL(merge_components_kernel<true>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
+        static const int diag_mode = [] { const char *e = getenv("BFF_MERGE_DIAG"); return e ? atoi(e) : 1; }();
+        if (diag && diag_mode == 2)   // block timeline only (BFF_MERGE_DIAG=2): production occupancy
+            hipExtLaunchKernelGGL(merge_components_kernel<2>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
+                rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
+                label_sorted, iou_thres, parent, nt, diag, list2, pass2, counts + 1, chunk_pop);
+        else if (diag)  // counters + phase clocks compiled in (a couple of registers more: one wave less per SIMD)
+            hipExtLaunchKernelGGL(merge_components_kernel<1>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
                 rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
                 label_sorted, iou_thres, parent, nt, diag, list2, pass2, counts + 1, chunk_pop);
         else
-            hipExtLaunchKernelGGL(merge_components_kernel<false>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
+            hipExtLaunchKernelGGL(merge_components_kernel<0>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
                 rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
                 label_sorted, iou_thres, parent, nt, (int32_t *)nullptr, list2, pass2, counts + 1, chunk_pop);
     }
