@@ -334,6 +334,9 @@ __global__ __launch_bounds__(256) void tile_masks_kernel(const uint64_t *__restr
 // applies the reference's float32 IoU test and emits adjacency words for the tile and its mirror
 // image, indexed by position in `order`.
 constexpr int kMaxChunks = 4096;     // chunk list capacity (LDS): N <= 4096*512 = 2.1 M points per call
+constexpr int kSplitStages = 12;     // split mode: LDS stages per part (a part = ~50 us of tile pass)
+constexpr int kMaxParts = 8;         // parts per tile pair
+constexpr int kMaxSlots = 512;       // tile pairs that can be split in one call (16 KiB of partial counts each)
 
 __global__ __launch_bounds__(256) void merge_adjacency_kernel(const uint64_t *__restrict__ rows, int n, int64_t nw,
                                                                const int32_t *__restrict__ order,
@@ -669,7 +672,10 @@ __global__ __launch_bounds__(256) void tile_pair_rows_kernel(const uint32_t *__r
                                                               const int32_t *__restrict__ list1,
                                                               const int32_t *__restrict__ count1,
                                                               int32_t *__restrict__ list2, uint64_t *__restrict__ pass2,
-                                                              int32_t *__restrict__ count2)
+                                                              int32_t *__restrict__ count2,
+                                                              const uint64_t *__restrict__ tmask, int mw,
+                                                              int32_t *__restrict__ part2, int32_t *__restrict__ n_slots,
+                                                              int list_cap)
 {
     const int lane = lane_id();
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -703,11 +709,28 @@ __global__ __launch_bounds__(256) void tile_pair_rows_kernel(const uint32_t *__r
     const uint64_t pa = __ballot(passes(uA, aA, aminB));
     const uint64_t pb = __ballot(passes(uB, aB, aminA));
     if (!pa || !pb) return;
+    // Tile pairs that share many chunks are the longest blocks of the tile pass (up to the whole cloud: 100 LDS
+    // stages); their chunk list is dealt to several blocks (kSplitStages stages each, at most kMaxParts) whose
+    // partial intersections meet in a scratch slot (merge_tile_pair, split mode).
+    int shared = 0;
+    if (tmask && lane < mw) shared = __popcll(tmask[(int64_t)bi * mw + lane] & tmask[(int64_t)bj * mw + lane]);
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) shared += __shfl_xor(shared, dd);
     if (lane == 0) {
-        const int at = atomicAdd(count2, 1);
-        list2[at] = t;
-        pass2[2 * at] = pa;
-        pass2[2 * at + 1] = pb;
+        int n_parts = 1, slot = 0;
+        if (part2 && shared >= 2 * kSplitStages * (kKW / kCW)) {
+            n_parts = min(kMaxParts, shared / (kSplitStages * (kKW / kCW)));
+            slot = atomicAdd(n_slots, 1);
+            if (slot >= kMaxSlots) n_parts = 1;                    // out of slots: one block, as before
+        }
+        const int at = atomicAdd(count2, n_parts);
+        if (at + n_parts > list_cap) return;                       // cannot happen with the caps chosen by the host
+        for (int p = 0; p < n_parts; ++p) {
+            list2[at + p] = t;
+            pass2[2 * (at + p)] = pa;
+            pass2[2 * (at + p) + 1] = pb;
+            if (part2) part2[at + p] = n_parts > 1 ? ((slot << 8) | (n_parts << 4) | p) : 0;
+        }
     }
 }
 
@@ -753,8 +776,15 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
                                                 const int32_t *__restrict__ area_sorted,
                                                 const int32_t *__restrict__ label_sorted, float thr,
                                                 int32_t *__restrict__ parent, int n_tiles,
-                                                int32_t *__restrict__ diag, const uint16_t *__restrict__ cpop)
+                                                int32_t *__restrict__ diag, const uint16_t *__restrict__ cpop,
+                                                int part_info, int32_t *__restrict__ partial, int32_t *__restrict__ arrive)
 {
+    // split mode (part_info != 0): this block is part `part` of `n_parts` of the tile pair and counts only every
+    // n_parts-th LDS stage of the chunk list.  All parts must agree on the candidate pairs, so those come from the
+    // static bounds alone (not from the forest, which changes while the parts run), nothing is settled early, and the
+    // partial counts are added into the pair's scratch slot; the part that arrives last reads the sums and decides.
+    const bool split = part_info != 0;
+    const int part = part_info & 15, n_parts = split ? (part_info >> 4) & 15 : 1, pslot = part_info >> 8;
     __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
     __shared__ uint16_t clist[kMaxChunks];
     __shared__ int s_cnt;
@@ -777,7 +807,7 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
         rowA[tid] = row;
         areaA[tid] = area_sorted[i0 + tid];
         labA[tid] = label_sorted[i0 + tid];
-        rootA[tid] = live ? uf_find(parent, row) : -1;
+        rootA[tid] = live ? (split ? row : uf_find(parent, row)) : -1;
     } else if (tid < 2 * kT) {
         const int k = tid - kT;
         const int row = row_sorted[j0 + k];
@@ -785,7 +815,7 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
         rowB[k] = row;
         areaB[k] = area_sorted[j0 + k];
         labB[k] = label_sorted[j0 + k];
-        rootB[k] = live ? uf_find(parent, row) : -2;
+        rootB[k] = live ? (split ? row : uf_find(parent, row)) : -2;
     }
     // histogram bound (see merge_adjacency_kernel): possible edges only.  hist holds two 16-bit bins per
     // word, so one v_pk_min_u16 + one v_dot2_u32_u16 accumulates two bins of sum_b min(hist_i, hist_j).
@@ -1021,7 +1051,20 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
     constexpr int kSparse = 3;                                     // pair-list path: at most 3 pairs per thread
     constexpr int kCheck = 2;                                      // settle pairs every kCheck stages
     if (kDiag) diag_lap(diag, 6, &t_lap);                                     // pair / chunk lists
-    if (cnt) fetch(0);
+    const int g_first = part * kStep, g_step = n_parts * kStep;    // split mode: every n_parts-th stage is this block's
+    __shared__ int s_last;
+    // split mode, after the chunk loop: add this part's counts to the slot; the last part to arrive takes the sums.
+    // Only read-modify-write atomics touch the slot (they are coherent across the chip's L2s); every thread's adds
+    // are complete (agent-scope fence) before thread 0 takes the ticket.
+    auto arrive_last = [&]() -> bool {
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(arrive + pslot, 1) == n_parts - 1;
+        __syncthreads();
+        return s_last != 0;                                        // block-uniform
+    };
+    int32_t *my_partial = split ? partial + (int64_t)pslot * (kT * kT) : nullptr;
+    if (g_first < cnt) fetch(g_first);
     if (n_pairs <= kSparse * 256) {
         // few candidates: accumulate only those pairs (2 LDS reads per pair word)
         int pi[kSparse], pj[kSparse], accs[kSparse];
@@ -1034,10 +1077,10 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
             if (p < n_pairs) open |= 1u << q;
         }
         int stages_done = 0;
-        for (int g = 0; g < cnt; g += kStep) {
+        for (int g = g_first; g < cnt; g += g_step) {
             stage();
             __syncthreads();
-            if (g + kStep < cnt) fetch(g + kStep);
+            if (g + g_step < cnt) fetch(g + g_step);
 #pragma unroll
             for (int q = 0; q < kSparse; ++q)
                 if ((open >> q) & 1) {
@@ -1046,8 +1089,10 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
                     for (int kk = 0; kk < kKW; ++kk) a2 += popc64(sa[kk][pi[q]] & sb[kk][pj[q]]);
                     accs[q] += a2;
                 }
-            const bool last = g + kStep >= cnt;
-            if (++stages_done % kCheck == 0 || last) {
+            const bool last = g + g_step >= cnt;
+            if (split) {
+                __syncthreads();
+            } else if (++stages_done % kCheck == 0 || last) {
 #pragma unroll
                 for (int q = 0; q < kSparse; ++q)
                     if (((open >> q) & 1) && settle(pi[q], pj[q], accs[q], last)) open &= ~(1u << q);
@@ -1056,6 +1101,18 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
                 if (!any_open) break;                              // every pair settled: the rest of the chunks is moot
             } else {
                 __syncthreads();
+            }
+        }
+        if (split) {
+#pragma unroll
+            for (int q = 0; q < kSparse; ++q)
+                if (((open >> q) & 1) && accs[q]) atomicAdd(my_partial + pi[q] * kT + pj[q], accs[q]);
+            if (arrive_last()) {
+#pragma unroll
+                for (int q = 0; q < kSparse; ++q)
+                    if ((open >> q) & 1) settle(pi[q], pj[q], atomicAdd(my_partial + pi[q] * kT + pj[q], 0), true);
+                __syncthreads();
+                flush();
             }
         }
         if (kDiag) diag_lap(diag, 7, &t_lap);                                 // pair-list pass (incl. its unions)
@@ -1075,10 +1132,10 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
     const int n_mine = min(kT * kT / 256, max(0, (n_pairs - tid + 255) / 256));
     unsigned open = (1u << n_mine) - 1;                            // bit q: pair tid + 256 q of plist is undecided
     int stages_done = 0;
-    for (int g = 0; g < cnt; g += kStep) {
+    for (int g = g_first; g < cnt; g += g_step) {
         stage();
         __syncthreads();
-        if (g + kStep < cnt) fetch(g + kStep);
+        if (g + g_step < cnt) fetch(g + g_step);
 #pragma unroll 8
         for (int kk = 0; kk < kKW; ++kk) {
             uint64_t av[4], bv[4];
@@ -1090,8 +1147,8 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
                 for (int c = 0; c < 4; ++c) acc[r][c] += popc64(av[r] & bv[c]);
         }
         __syncthreads();
-        const bool last = g + kStep >= cnt;
-        if (++stages_done % kCheck == 0 || last) {
+        const bool last = g + g_step >= cnt;
+        if (!split && (++stages_done % kCheck == 0 || last)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -1108,6 +1165,33 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
             const int any_open = __syncthreads_or(open != 0);
             flush();
             if (!any_open) break;
+        }
+    }
+    if (split) {
+        // this part's counts go through the LDS image (as in a settle phase) and are added pair by pair: a rolled loop
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cnts[ti * 4 + r][tj * 4 + c] = acc[r][c];
+        __syncthreads();
+#pragma unroll 1
+        for (int q = 0; q < kT * kT / 256; ++q) {
+            const int p = tid + q * 256;
+            if (p >= n_pairs) break;
+            const int code = plist[p];
+            const int v = cnts[code >> 8][code & 255];
+            if (v) atomicAdd(my_partial + (code >> 8) * kT + (code & 255), v);
+        }
+        if (arrive_last()) {
+#pragma unroll 1
+            for (int q = 0; q < kT * kT / 256; ++q) {
+                const int p = tid + q * 256;
+                if (p >= n_pairs) break;
+                const int code = plist[p];
+                settle(code >> 8, code & 255, atomicAdd(my_partial + (code >> 8) * kT + (code & 255), 0), true);
+            }
+            __syncthreads();
+            flush();
         }
     }
     if (kDiag) diag_lap(diag, 8, &t_lap);                                     // dense pass (incl. its unions)
@@ -1130,13 +1214,16 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
                                                                 const int32_t *__restrict__ list,
                                                                 const uint64_t *__restrict__ pass,
                                                                 const int32_t *__restrict__ count,
-                                                                const uint16_t *__restrict__ cpop)
+                                                                const uint16_t *__restrict__ cpop,
+                                                                const int32_t *__restrict__ part2,
+                                                                int32_t *__restrict__ partial, int32_t *__restrict__ arrive)
 {
     if ((int)blockIdx.x >= *count) return;                         // block-uniform
     long long t_start = 0;
     if (kMode) t_start = (long long)__builtin_amdgcn_s_memrealtime();    // 100 MHz, one clock for the whole chip
     merge_tile_pair<kMode == 1>(list[blockIdx.x], pass[2 * blockIdx.x], pass[2 * blockIdx.x + 1], rows, n, nw, tmask, mw, hist,
-                                n_pos, row_sorted, area_sorted, label_sorted, thr, parent, n_tiles, kMode == 1 ? diag : nullptr, cpop);
+                                n_pos, row_sorted, area_sorted, label_sorted, thr, parent, n_tiles, kMode == 1 ? diag : nullptr, cpop,
+                                part2 ? part2[blockIdx.x] : 0, partial, arrive);
     if (kMode && threadIdx.x == 0 && diag[15] > 0 && (int)blockIdx.x < diag[15]) {
         // block timeline (diag[15] = capacity): start / end in 10-ns ticks (low 32 bits), at diag[16 + 2 b]
         diag[16 + 2 * blockIdx.x] = (int32_t)t_start;
@@ -1862,12 +1949,20 @@ extern "C" int32_t bff_merge_uses_chunk_bound(int64_t nw)
     return ceil_div(nw > 0 ? nw : 1, kBins) >= 16 * kCW;
 }
 
+// entries of the second tile-pair list: every surviving pair once + the extra parts of the pairs that are split
+static int64_t merge_list_cap(int64_t total)
+{
+    return total + (int64_t)(kMaxParts - 1) * (total < kMaxSlots ? total : kMaxSlots);
+}
+
 extern "C" int64_t bff_merge_scratch_words(int32_t n_rows)
 {
     const int64_t nt = ceil_div(n_rows > 0 ? n_rows : 1, kT), n_pos = nt * kT, total = nt * (nt + 1) / 2;
-    // sorted histogram, tile maxima, tile minima, three position-indexed row tables, two counters (+ padding),
-    // list 1, list 2, and two 64-bit pass masks per list-2 entry
-    return (kBins / 2) * n_pos + kBins * nt + nt + 3 * n_pos + 4 + total + total + 4 * total + 2;
+    const int64_t cap2 = merge_list_cap(total);
+    // sorted histogram, tile maxima, tile minima, three position-indexed row tables, counters (+ padding), list 1,
+    // list 2 with two 64-bit pass masks and a part word per entry, arrival counters and 64 x 64 partial counts per slot
+    return (kBins / 2) * n_pos + kBins * nt + nt + 3 * n_pos + 4 + total + cap2 + 4 * cap2 + 2 + cap2 + 4 +
+           (int64_t)kMaxSlots * (kT * kT + 1);
 }
 
 extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
@@ -1901,9 +1996,18 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
         int32_t *label_sorted = area_sorted + n_pos;
         int32_t *counts = label_sorted + n_pos;                        // [0] list 1, [1] list 2
         int32_t *list1 = counts + 4;
+        const int64_t cap2 = merge_list_cap(total);
+        BFF_LIMIT(cap2 < (1ll << 31), "bff_merge_components: too many rows");
         int32_t *list2 = list1 + total;
-        uintptr_t p2 = reinterpret_cast<uintptr_t>(list2 + total);
+        uintptr_t p2 = reinterpret_cast<uintptr_t>(list2 + cap2);
         uint64_t *pass2 = reinterpret_cast<uint64_t *>((p2 + 7) & ~(uintptr_t)7);
+        int32_t *part2 = reinterpret_cast<int32_t *>(pass2 + 2 * cap2);
+        int32_t *arrive = part2 + cap2;                                // [kMaxSlots], then the slots' partial counts
+        int32_t *partial = arrive + kMaxSlots;
+        // heavy tile pairs are split over several blocks unless switched off (BFF_MERGE_SPLIT=0); thr < 0 visits every
+        // chunk of every pair anyway and keeps the simple form
+        static const bool split_on = [] { const char *e = getenv("BFF_MERGE_SPLIT"); return !e || atoi(e) != 0; }();
+        const bool do_split = split_on && sparse;
         tile_masks_kernel<<<nt, 256, 0, st>>>(chunk_mask, order, n_order, mw, tile_mask, hist, hist_sorted, (int)n_pos, area,
                                              tile_hmax, tile_amin, label_id, row_sorted, area_sorted, label_sorted);
         // Pre-pass over pairs 1, 2, 3, 5 apart in the tile order: it used to shorten the tile pass when every proven
@@ -1920,27 +2024,29 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
                                                       parent, kStrides);
         }
         hipError_t e = hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), st);
+        if (e == hipSuccess && do_split) e = hipMemsetAsync(arrive, 0, sizeof(int32_t) * (size_t)kMaxSlots * (kT * kT + 1), st);
         if (e != hipSuccess) return fail((int)e, "bff_merge_components: memset: %s", hipGetErrorString(e));
         tile_pair_filter_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(tile_hmax, tile_amin, nt, (int)total,
                                                                                iou_thres, list1, counts);
         tile_pair_rows_kernel<<<(unsigned)ceil_div(total, 4), 256, 0, st>>>(hist_sorted, (int)n_pos, area_sorted, tile_hmax,
                                                                            tile_amin, nt, iou_thres, list1, counts,
-                                                                           list2, pass2, counts + 1);
+                                                                           list2, pass2, counts + 1, sparse ? tile_mask : nullptr,
+                                                                           mw, do_split ? part2 : nullptr, counts + 2, (int)cap2);
         const hipEvent_t ev0 = g_merge_start, ev1 = g_merge_stop;      // attached to the dispatch itself when set
         g_merge_start = g_merge_stop = nullptr;
         static const int diag_mode = [] { const char *e = getenv("BFF_MERGE_DIAG"); return e ? atoi(e) : 1; }();
         if (diag && diag_mode == 2)   // block timeline only (BFF_MERGE_DIAG=2): production occupancy
-            hipExtLaunchKernelGGL(merge_components_kernel<2>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
+            hipExtLaunchKernelGGL(merge_components_kernel<2>, dim3((unsigned)cap2), dim3(256), 0, st, ev0, ev1, 0,
                 rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
-                label_sorted, iou_thres, parent, nt, diag, list2, pass2, counts + 1, chunk_pop);
+                label_sorted, iou_thres, parent, nt, diag, list2, pass2, counts + 1, chunk_pop, do_split ? part2 : nullptr, partial, arrive);
         else if (diag)  // counters + phase clocks compiled in (a couple of registers more: one wave less per SIMD)
-            hipExtLaunchKernelGGL(merge_components_kernel<1>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
+            hipExtLaunchKernelGGL(merge_components_kernel<1>, dim3((unsigned)cap2), dim3(256), 0, st, ev0, ev1, 0,
                 rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
-                label_sorted, iou_thres, parent, nt, diag, list2, pass2, counts + 1, chunk_pop);
+                label_sorted, iou_thres, parent, nt, diag, list2, pass2, counts + 1, chunk_pop, do_split ? part2 : nullptr, partial, arrive);
         else
-            hipExtLaunchKernelGGL(merge_components_kernel<0>, dim3((unsigned)total), dim3(256), 0, st, ev0, ev1, 0,
+            hipExtLaunchKernelGGL(merge_components_kernel<0>, dim3((unsigned)cap2), dim3(256), 0, st, ev0, ev1, 0,
                 rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
-                label_sorted, iou_thres, parent, nt, (int32_t *)nullptr, list2, pass2, counts + 1, chunk_pop);
+                label_sorted, iou_thres, parent, nt, (int32_t *)nullptr, list2, pass2, counts + 1, chunk_pop, do_split ? part2 : nullptr, partial, arrive);
     }
     if (comp) uf_flatten_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows, comp);
     return launched("bff_merge_components");

@@ -77,14 +77,15 @@ def pack_rles(rles, expect_length, staging: Staging, tag, n_threads=4):
     """RLE dicts -> (run_start, run_end, offs) int32 pinned views, or None when the native fast path declines
     (unsorted / overlapping runs etc.: the caller uses scene.runs_from_rles)."""
     n = len(rles)
-    cap = 0
-    for r in rles:
-        cap += r["counts"].size if hasattr(r["counts"], "size") else len(r["counts"])
-    cap //= 2
-    rs = staging.get(tag + ".start", 4 * max(cap, 1)).view(torch.int32)
-    re = staging.get(tag + ".end", 4 * max(cap, 1)).view(torch.int32)
     offs = staging.get(tag + ".offs", 4 * (n + 1)).view(torch.int32)
-    got = host_lib().bff_host_pack_rles(rles, rs.data_ptr(), re.data_ptr(), cap, offs.data_ptr(), int(expect_length), n_threads)
+    cap = max(staging.buf[tag + ".start"].numel() // 4 if tag + ".start" in staging.buf else 0, 1 << 16)
+    while True:                                   # the native builder reports -2 when the tables are too small: grow
+        rs = staging.get(tag + ".start", 4 * cap).view(torch.int32)
+        re = staging.get(tag + ".end", 4 * cap).view(torch.int32)
+        got = host_lib().bff_host_pack_rles(rles, rs.data_ptr(), re.data_ptr(), cap, offs.data_ptr(), int(expect_length), n_threads)
+        if got != -2:
+            break
+        cap *= 2
     if got == -4:
         raise ValueError("2-D mask RLE with start < 1 (negative python slice in the reference decoder)")
     if got == -3:
@@ -290,7 +291,7 @@ class Ingestor:
     (`stream.wait_event`) -- it never blocks on the upload itself -- so the host->device traffic of scene i+1 runs
     under the kernels of scene i."""
 
-    def __init__(self, cfg, device, n_loaders=2, native_threads=4, with_viewed=True):
+    def __init__(self, cfg, device, n_loaders=4, native_threads=4, with_viewed=True):
         self.cfg, self.device = cfg, torch.device(device)
         self.with_viewed = with_viewed
         self.native_threads = native_threads
@@ -322,7 +323,7 @@ class Ingestor:
         self.pool.shutdown(wait=True)
 
 
-def bench_host_inclusive(scenes, cfg, device, query, sim, steps=40, n_loaders=2, native_threads=4):
+def bench_host_inclusive(scenes, cfg, device, query, sim, steps=40, n_loaders=4, native_threads=4):
     """Scenes/s from HOST arrays: every step takes a scene in the reference's host formats (float64 cloud, RLE dicts,
     poses, raw 16-bit depth frames as the PNGs store them -- here at half the working resolution, ScanNet's sensor
     ratio -- scaled and resized on the device as P:432-436) through the ingestion pipeline and then through the same
