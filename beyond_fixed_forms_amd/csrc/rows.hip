@@ -767,6 +767,8 @@ __device__ __forceinline__ bool local_union(int *lid, int a, int b)
     }
 }
 
+__shared__ int g_block_info[2];        // [0] candidate pairs | shared chunks << 16, [1] LDS stages executed (diagnostics)
+
 template <bool kDiag>
 __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t pass_b,
                                                 const uint64_t *__restrict__ rows, int n, int64_t nw,
@@ -976,6 +978,7 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
     int pos = incl - mine_n;
     for (int q = 0; q < wv; ++q) pos += wbase[q];
     const int n_pairs = wbase[0] + wbase[1] + wbase[2] + wbase[3];
+    if (tid == 0) g_block_info[0] = n_pairs | (s_cnt << 16);      // timeline diagnostics (mode 2) read this
     {
         unsigned cc = cand;
         while (cc) {
@@ -1049,7 +1052,9 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
     };
     constexpr int kStep = kKW / kCW;                               // chunks per stage
     constexpr int kSparse = 3;                                     // pair-list path: at most 3 pairs per thread
-    constexpr int kCheck = 2;                                      // settle pairs every kCheck stages
+    // settle pairs every `check_every` stages: 2 at first; a settle phase that closes no pair doubles the interval
+    // (tiles between two groups of one object never settle early: their phases would cost as much as the counting)
+    int check_every = 2, next_check = 2;
     if (kDiag) diag_lap(diag, 6, &t_lap);                                     // pair / chunk lists
     const int g_first = part * kStep, g_step = n_parts * kStep;    // split mode: every n_parts-th stage is this block's
     __shared__ int s_last;
@@ -1079,6 +1084,7 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
         int stages_done = 0;
         for (int g = g_first; g < cnt; g += g_step) {
             stage();
+            if (tid == 0) g_block_info[1] += 1;
             __syncthreads();
             if (g + g_step < cnt) fetch(g + g_step);
 #pragma unroll
@@ -1092,13 +1098,17 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
             const bool last = g + g_step >= cnt;
             if (split) {
                 __syncthreads();
-            } else if (++stages_done % kCheck == 0 || last) {
+            } else if (++stages_done == next_check || last) {
+                const unsigned before_open = open;
 #pragma unroll
                 for (int q = 0; q < kSparse; ++q)
                     if (((open >> q) & 1) && settle(pi[q], pj[q], accs[q], last)) open &= ~(1u << q);
                 const int any_open = __syncthreads_or(open != 0);
+                const int progress = __syncthreads_or(open != before_open);
                 flush();
                 if (!any_open) break;                              // every pair settled: the rest of the chunks is moot
+                if (!progress) check_every *= 2;
+                next_check = stages_done + check_every;
             } else {
                 __syncthreads();
             }
@@ -1134,6 +1144,7 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
     int stages_done = 0;
     for (int g = g_first; g < cnt; g += g_step) {
         stage();
+        if (tid == 0) g_block_info[1] += 0x10000;                 // dense stages count in the upper half
         __syncthreads();
         if (g + g_step < cnt) fetch(g + g_step);
 #pragma unroll 8
@@ -1148,7 +1159,8 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
         }
         __syncthreads();
         const bool last = g + g_step >= cnt;
-        if (!split && (++stages_done % kCheck == 0 || last)) {
+        if (!split && (++stages_done == next_check || last)) {
+            const unsigned before_open = open;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -1163,8 +1175,11 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
                 if (settle(code >> 8, code & 255, cnts[code >> 8][code & 255], last)) open &= ~(1u << q);
             }
             const int any_open = __syncthreads_or(open != 0);
+            const int progress = __syncthreads_or(open != before_open);
             flush();
             if (!any_open) break;
+            if (!progress) check_every *= 2;
+            next_check = stages_done + check_every;
         }
     }
     if (split) {
@@ -1221,6 +1236,7 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
     if ((int)blockIdx.x >= *count) return;                         // block-uniform
     long long t_start = 0;
     if (kMode) t_start = (long long)__builtin_amdgcn_s_memrealtime();    // 100 MHz, one clock for the whole chip
+    if (threadIdx.x == 0) { g_block_info[0] = 0; g_block_info[1] = 0; }
     merge_tile_pair<kMode == 1>(list[blockIdx.x], pass[2 * blockIdx.x], pass[2 * blockIdx.x + 1], rows, n, nw, tmask, mw, hist,
                                 n_pos, row_sorted, area_sorted, label_sorted, thr, parent, n_tiles, kMode == 1 ? diag : nullptr, cpop,
                                 part2 ? part2[blockIdx.x] : 0, partial, arrive);
@@ -1228,6 +1244,10 @@ __global__ __launch_bounds__(256) void merge_components_kernel(const uint64_t *_
         // block timeline (diag[15] = capacity): start / end in 10-ns ticks (low 32 bits), at diag[16 + 2 b]
         diag[16 + 2 * blockIdx.x] = (int32_t)t_start;
         diag[17 + 2 * blockIdx.x] = (int32_t)(long long)__builtin_amdgcn_s_memrealtime();
+        if (kMode == 2 && diag[14] > 0) {          // diag[14] != 0: two more words per block behind the timeline
+            diag[16 + 2 * diag[15] + 2 * blockIdx.x] = g_block_info[0];
+            diag[17 + 2 * diag[15] + 2 * blockIdx.x] = g_block_info[1];
+        }
     }
 }
 

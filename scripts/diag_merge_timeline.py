@@ -25,11 +25,15 @@ area, mw_, cmask, hist, sig = _lib.row_stats(rows, fr.cmask)
 order = _lib.argsort_i64(sig, 30)
 cap = 60000
 for rep in range(2):
-    d = torch.zeros(16 + 2 * cap, dtype=torch.int32, device=dev)
+    d = torch.zeros(16 + 4 * cap, dtype=torch.int32, device=dev)
     d[15] = cap
+    d[14] = 1
     _lib.merge_components(rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist, diag=d)
 tl = d[16:16 + 2 * cap].view(-1, 2).cpu().numpy().astype("int64") & 0xffffffff
+info = d[16 + 2 * cap:16 + 4 * cap].view(-1, 2).cpu().numpy().astype("int64")
 idx = np.flatnonzero(tl[:, 1] != 0)
+info = info[idx]
+n_pairs, shared, sparse_stages, dense_stages = info[:, 0] & 0xffff, info[:, 0] >> 16, info[:, 1] & 0xffff, info[:, 1] >> 16
 tl = tl[idx]
 t0 = tl[:, 0].min()
 st, en = (tl[:, 0] - t0) * 0.01, (tl[:, 1] - t0) * 0.01
@@ -46,3 +50,16 @@ for lo in range(0, len(idx), max(1, len(idx) // 10)):
           f"duration mean {dur[sel].mean():6.1f} max {dur[sel].max():6.1f} us")
 late = np.argsort(-en)[:8]
 print("last blocks to finish (list position, start, duration):", [(int(idx[i]), round(float(st[i]), 1), round(float(dur[i]), 1)) for i in late])
+
+order_ = np.argsort(-dur)[:25]
+print("longest blocks: (duration us, candidate pairs, shared chunks, sparse stages, dense stages)")
+for i in order_:
+    print(f"   {dur[i]:7.1f}  pairs {n_pairs[i]:5d}  chunks {shared[i]:4d}  sparse {sparse_stages[i]:3d}  dense {dense_stages[i]:3d}  start {st[i]:6.1f}")
+reached = n_pairs > 0
+print(f"blocks that reached the exact stage: {int(reached.sum())}; of all block time {dur[reached].sum() / dur.sum() * 100:.0f} % is theirs; "
+      f"time per stage (their time / their stages): {dur[reached].sum() / max(1, (sparse_stages + dense_stages)[reached].sum()):.2f} us")
+for name, sel in (("sparse", reached & (dense_stages == 0)), ("dense", dense_stages > 0)):
+    if sel.any():
+        print(f"  {name}: {int(sel.sum())} blocks, {dur[sel].sum() / 1e3:.1f} ms, stages {int((sparse_stages + dense_stages)[sel].sum())}, "
+              f"{dur[sel].sum() / max(1, (sparse_stages + dense_stages)[sel].sum()):.2f} us per stage, mean shared chunks {shared[sel].mean():.0f}")
+print(f"  blocks that stopped at the bounds: {int((~reached).sum())}, {dur[~reached].sum() / 1e3:.1f} ms, mean {dur[~reached].mean():.1f} us")
