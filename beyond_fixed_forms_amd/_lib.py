@@ -54,7 +54,7 @@ SIGNATURES = {
     "bff_normalized_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
     "bff_description_means": [_P, _P, _I, _I, _I, _P, _P],
     "bff_group_components": [_P, _P, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
-    "bff_or_reduce_grouped": [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
+    "bff_or_reduce_grouped": [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "bff_resolve_overlaps_dev": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "bff_clear_flagged_chunks_unless": [_P, _I, _L, _P, _P, _P],
     "bff_scene_project": [_P, _P, _P, _P],
@@ -329,6 +329,16 @@ def permute_bits(rows, idx, n_out, out=None):
     if out is None:
         out = torch.empty((rows.shape[0], nw_out), dtype=i64, device=rows.device)
     call("bff_permute_bits", _ptr(rows, i64), rows.shape[0], rows.shape[1], _ptr(idx, i32), n_out, nw_out, _ptr(out))
+    return out
+
+
+def scatter_bits(rows, perm, n_out, out=None):
+    """out[r] bit perm[s] = rows[r] bit s for the set bits only (undoes the spatial point sort; `out` is zeroed here
+    unless given, in which case it must be zero).  perm: int32 [n], original index of sorted position s."""
+    nw_out = (n_out + 63) // 64
+    if out is None:
+        out = torch.zeros((rows.shape[0], nw_out), dtype=i64, device=rows.device)
+    call("bff_scatter_bits", _ptr(rows, i64), rows.shape[0], rows.shape[1], _ptr(perm, i32), n_out, nw_out, _ptr(out), None)
     return out
 
 

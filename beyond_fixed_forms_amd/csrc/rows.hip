@@ -1486,9 +1486,10 @@ __global__ __launch_bounds__(256) void or_reduce_grouped_kernel(const uint64_t *
                                                                  const int32_t *__restrict__ members,
                                                                  const int32_t *__restrict__ slices, int slice_cap,
                                                                  uint64_t *__restrict__ out, const T *__restrict__ conf,
-                                                                 T *__restrict__ mean)
+                                                                 T *__restrict__ mean, const uint64_t *__restrict__ cmask, int mw)
 {
     __shared__ T stage[1024];
+    __shared__ uint32_t s_occ[kOrSplit];           // cmask given: the 32 chunk flags of every member for this block's 256 words
     if (blockIdx.y == 0) {
         if (conf && threadIdx.x < kWave) {
             const int k = min(info[0], cap);
@@ -1499,11 +1500,25 @@ __global__ __launch_bounds__(256) void or_reduce_grouped_kernel(const uint64_t *
     const int sidx = (int)blockIdx.y - 1;
     if (sidx >= info[3]) return;
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nw) return;
+    if (w >= nw && !cmask) return;
     const int g = slices[sidx], lo = slices[slice_cap + sidx], hi = slices[2 * slice_cap + sidx];
     uint64_t v = 0;
+    if (cmask) {
+        // long rows (~1 % occupied): a block's 256 words are 32 chunks = one 32-bit piece of a member's chunk flags;
+        // a member's word is loaded only where the member has points
+        if (threadIdx.x < hi - lo) {
+            const uint64_t m64 = cmask[(int64_t)members[lo + threadIdx.x] * mw + (blockIdx.x >> 1)];
+            s_occ[threadIdx.x] = (uint32_t)(m64 >> (32 * (blockIdx.x & 1)));
+        }
+        __syncthreads();
+        const int c = threadIdx.x >> 3;                            // chunk of this thread's word within the block
+        if (w < nw)
+            for (int m = lo; m < hi; ++m)
+                if ((s_occ[m - lo] >> c) & 1) v |= rows[(int64_t)members[m] * nw + w];
+    } else {
 #pragma unroll 8
-    for (int m = lo; m < hi; ++m) v |= rows[(int64_t)members[m] * nw + w];
+        for (int m = lo; m < hi; ++m) v |= rows[(int64_t)members[m] * nw + w];
+    }
     if (v) atomicOr((unsigned long long *)(out + (int64_t)g * nw + w), (unsigned long long)v);
 }
 
@@ -1511,34 +1526,74 @@ __global__ __launch_bounds__(256) void or_reduce_grouped_kernel(const uint64_t *
 // Sequential overlap decisions of solve_overlapping (P:285-299) on the device: inter is the K x K
 // intersection matrix of the aggregated rows BEFORE any edit (P:289-292), size[i] the number of raw masks
 // merged into row i; pairs are visited in the reference's order (i ascending, j > i ascending) and the
-// and-not operations appended to `ops` ([0] = count, then (opcode, dst, src) triples).  One thread: K is
-// tens to a few hundred and the list order is the semantics.
-constexpr int kOvlMax = 96;      // K x K flags staged in LDS when K <= 96 (9 KB); larger K reads global memory
+// and-not operations appended to `ops` ([0] = count, then (opcode, dst, src) triples).
+constexpr int kOvlRows = 8192;   // rows whose pair counts fit the block's LDS; beyond that one thread walks the pairs
 
-__global__ __launch_bounds__(256) void overlap_ops_kernel(const int32_t *__restrict__ inter,
-                                                           const int32_t *__restrict__ size, int k,
-                                                           int32_t *__restrict__ ops)
+// One block: (1) wave w counts, for its rows i = w, w + 16, ..., the rows j > i with inter[i][j] > 0 (ballots over 64
+// columns at a time), (2) a block-wide exclusive scan turns the counts into list offsets -- the reference visits the
+// pairs in (i ascending, j ascending) order and that IS the order of (offset of i, rank of j within i), (3) the waves
+// walk their rows again and write the triples.  The order of the list is the semantics (P:285-299); building it is
+// embarrassingly parallel.
+__global__ __launch_bounds__(1024) void overlap_ops_kernel(const int32_t *__restrict__ inter,
+                                                            const int32_t *__restrict__ size, int k,
+                                                            int32_t *__restrict__ ops)
 {
-    __shared__ uint8_t s_ovl[kOvlMax * kOvlMax];
-    __shared__ int s_size[kOvlMax];
-    const bool staged = k <= kOvlMax;
-    if (staged) {                                  // all threads stage, one thread replays the ordered loop
-        for (int i = threadIdx.x; i < k * k; i += blockDim.x) s_ovl[i] = inter[i] > 0;
-        for (int i = threadIdx.x; i < k; i += blockDim.x) s_size[i] = size[i];
+    __shared__ int s_cnt[kOvlRows];
+    __shared__ int s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (k > kOvlRows) {                            // not a realistic size: the plain ordered loop
+        if (tid) return;
+        int n = 0;
+        for (int i = 0; i < k; ++i)
+            for (int j = i + 1; j < k; ++j)
+                if (inter[(int64_t)i * k + j] > 0) {
+                    const bool i_wins = size[i] > size[j];            // ties: i loses (P:296-299)
+                    ops[1 + 3 * n] = 0; ops[2 + 3 * n] = i_wins ? j : i; ops[3 + 3 * n] = i_wins ? i : j;
+                    ++n;
+                }
+        ops[0] = n;
+        return;
+    }
+    for (int i = wave; i < k; i += 16) {
+        int c = 0;
+        for (int j0 = (i + 1) & ~63; j0 < k; j0 += 64) {
+            const int j = j0 + lane;
+            c += __popcll(__ballot(j > i && j < k && inter[(int64_t)i * k + j] > 0));
+        }
+        if (lane == 0) s_cnt[i] = c;
     }
     __syncthreads();
-    if (threadIdx.x) return;
-    int n = 0;
-    for (int i = 0; i < k; ++i)
-        for (int j = i + 1; j < k; ++j)
-            if (staged ? s_ovl[i * k + j] : (inter[(int64_t)i * k + j] > 0)) {
-                const bool i_wins = (staged ? s_size[i] > s_size[j] : size[i] > size[j]);   // ties: i loses (P:296-299)
+    // exclusive scan of s_cnt[0..k) in place: thread t owns a contiguous run of ceil(k / 1024) rows
+    const int per = (k + 1023) / 1024, lo = tid * per, hi = min(k, lo + per);
+    int mine = 0;
+    for (int i = lo; i < hi; ++i) mine += s_cnt[i];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - mine;
+    for (int q = 0; q < wave; ++q) base += s_wsum[q];
+    if (tid == 1023) ops[0] = base + mine;
+    for (int i = lo; i < hi; ++i) { const int c = s_cnt[i]; s_cnt[i] = base; base += c; }
+    __syncthreads();
+    for (int i = wave; i < k; i += 16) {
+        int at = s_cnt[i];
+        const int size_i = size[i];
+        for (int j0 = (i + 1) & ~63; j0 < k; j0 += 64) {
+            const int j = j0 + lane;
+            const bool on = j > i && j < k && inter[(int64_t)i * k + j] > 0;
+            const uint64_t bal = __ballot(on);
+            if (on) {
+                const int n = at + __popcll(bal & ((1ull << lane) - 1));
+                const bool i_wins = size_i > size[j];                 // ties: i loses (P:296-299)
                 ops[1 + 3 * n] = 0;
                 ops[2 + 3 * n] = i_wins ? j : i;
                 ops[3 + 3 * n] = i_wins ? i : j;
-                ++n;
             }
-    ops[0] = n;
+            at += __popcll(bal);
+        }
+    }
 }
 
 __global__ void apply_row_ops_kernel(uint64_t *__restrict__ rows, int64_t nw, const int32_t *__restrict__ ops,
@@ -2138,7 +2193,7 @@ extern "C" int bff_overlap_ops(const int32_t *inter, const int32_t *size, int32_
 {
     BFF_REQUIRE(k >= 0, "bff_overlap_ops: bad size");
     BFF_REQUIRE(ops && (k == 0 || (inter && size)), "bff_overlap_ops: null pointer");
-    overlap_ops_kernel<<<1, 256, 0, as_stream(stream)>>>(inter, size, k, ops);
+    overlap_ops_kernel<<<1, 1024, 0, as_stream(stream)>>>(inter, size, k, ops);
     return launched("bff_overlap_ops");
 }
 
@@ -2306,7 +2361,8 @@ extern "C" int bff_group_components(const int32_t *comp, const int32_t *area, in
 
 extern "C" int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n_rows, const int32_t *info, int32_t cap,
                                      const int32_t *offs, const int32_t *members, const int32_t *slices, uint64_t *out,
-                                     const void *conf, int32_t conf_dtype, void *conf_mean, void *stream)
+                                     const void *conf, int32_t conf_dtype, void *conf_mean, const uint64_t *chunk_mask,
+                                     void *stream)
 {
     BFF_REQUIRE(nw >= 0 && n_rows >= 0 && cap > 0, "bff_or_reduce_grouped: bad sizes");
     BFF_REQUIRE(rows && info && offs && members && slices && out, "bff_or_reduce_grouped: null pointer");
@@ -2320,12 +2376,16 @@ extern "C" int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n
     const int slice_cap = bff_group_slice_cap(n_rows, cap);
     dim3 grid((unsigned)ceil_div(nw > 0 ? nw : 1, 256), (unsigned)(slice_cap + 1));
     BFF_LIMIT(slice_cap + 1 <= 65535, "bff_or_reduce_grouped: too many member slices");
+    // through the chunk flags only when the rows are long (config 2: the dense pass runs at HBM speed and the flagged
+    // form was measured slower; config 4: 4.8 GB of rows, ~1 % occupied)
+    const uint64_t *cm = (chunk_mask && nw >= 8192) ? chunk_mask : nullptr;
+    const int mw = (int)ceil_div(ceil_div(nw, kCW), 64);
     if (conf_dtype == 1)
         or_reduce_grouped_kernel<__half><<<grid, 256, 0, st>>>(rows, nw, info, cap, offs, members, slices, slice_cap, out,
-                                                              (const __half *)conf, (__half *)conf_mean);
+                                                              (const __half *)conf, (__half *)conf_mean, cm, mw);
     else
         or_reduce_grouped_kernel<float><<<grid, 256, 0, st>>>(rows, nw, info, cap, offs, members, slices, slice_cap, out,
-                                                             (const float *)conf, (float *)conf_mean);
+                                                             (const float *)conf, (float *)conf_mean, cm, mw);
     return launched("bff_or_reduce_grouped");
 }
 

@@ -114,7 +114,7 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     BFF_TRY(bff_group_components(ws->comp, ws->area, n_rows, pr->iou_thres, pr->min_members, cap, ws->count, 1, info,
                                  hdr + BFF_HDR_SIZES, hdr + BFF_HDR_FIRST, ws->goffs, ws->gmembers, ws->slices, stream));
     BFF_TRY(bff_or_reduce_grouped(ws->rows, nw, n_rows, info, cap, ws->goffs, ws->gmembers, ws->slices, ws->agg, sc->conf,
-                                  sc->conf_f16, hdr + BFF_HDR_CONF, stream));
+                                  sc->conf_f16, hdr + BFF_HDR_CONF, ws->chunk_mask, stream));
     // last reader of the raw rows is done: give the arena its zeros back -- unless the host has to take the general
     // path (more groups than the device forms), which reads the rows again and clears them itself
     BFF_TRY(bff_clear_flagged_chunks_unless(ws->rows, n_rows, nw, ws->chunk_mask, info + 1, stream));

@@ -411,7 +411,12 @@ def _projection_back(fr: _Front, timers, phases, stage1=None) -> Stage2Result:
     rows, masked, viewed, keep, do_ratio = fr.rows, fr.masked, fr.viewed, fr.keep, fr.do_ratio
     # per-point arrays and bit rows are in the (spatially sorted) device point order; `unsorted` maps
     # bit rows back to the caller's point order
-    unsorted = (lambda r: _lib.permute_bits(r, ds.unsort, n)) if ds.unsort is not None else (lambda r: r)
+    if ds.unsort is None:
+        unsorted = lambda r: r
+    elif ds.perm is not None:           # scatter of the set bits: aggregated rows hold a few percent of the points
+        unsorted = lambda r: _lib.scatter_bits(r, ds.perm, n)
+    else:
+        unsorted = lambda r: _lib.permute_bits(r, ds.unsort, n)
     back = (lambda v: v[ds.unsort.long()]) if ds.unsort is not None else (lambda v: v.clone())
     if debug_out:
         dbg["raw_rows"], dbg["masked_counts_raw"] = unsorted(rows), back(masked)
@@ -477,10 +482,13 @@ def _projection_back(fr: _Front, timers, phases, stage1=None) -> Stage2Result:
         k_all, s1_n = agg.shape[0], stage1.row_run_offs.shape[0] - 1
         both = torch.empty((k_all + s1_n, ds.nw), dtype=torch.int64, device=dev)
         agg_u, s1 = both[:k_all], both[k_all:]
-        if ds.unsort is not None:
-            _lib.permute_bits(agg, ds.unsort, n, out=agg_u)
-        else:
+        if ds.unsort is None:
             agg_u.copy_(agg)
+        elif ds.perm is not None:
+            agg_u.zero_()
+            _lib.scatter_bits(agg, ds.perm, n, out=agg_u)
+        else:
+            _lib.permute_bits(agg, ds.unsort, n, out=agg_u)
         _lib.rle_to_rows(stage1.run_start, stage1.run_end, stage1.row_run_offs, n, out=s1)
         cross = _lib.cross_popcount(s1, both)                        # [S1][K + S1]
         before_h, after_h, conf_h, cross_h = _lib.fetch(before, after, conf, cross)

@@ -408,10 +408,10 @@ int bff_group_components(const int32_t *comp, const int32_t *area, int32_t n_row
                          int32_t min_members, int32_t cap, int32_t *count, int32_t count_is_zero, int32_t *info,
                          int32_t *sizes, int32_t *first, int32_t *offs, int32_t *members, int32_t *slices, void *stream);
 /* bff_or_reduce_groups for those groups: out [cap][nw] (zeroed here; rows >= K stay zero), conf_mean [cap] in the
- * confidence dtype. */
+ * confidence dtype.  chunk_mask (optional, the rows' chunk flags): long rows are read through it. */
 int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n_rows, const int32_t *info, int32_t cap,
                           const int32_t *offs, const int32_t *members, const int32_t *slices, uint64_t *out,
-                          const void *conf, int32_t conf_dtype, void *conf_mean, void *stream);
+                          const void *conf, int32_t conf_dtype, void *conf_mean, const uint64_t *chunk_mask, void *stream);
 /* bff_resolve_overlaps with the row count on the device (*k_dev <= k_cap, else nothing is touched); inter is
  * [k_cap][k_cap]. */
 int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *inter, const int32_t *size,
