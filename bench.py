@@ -242,30 +242,32 @@ def merge_traffic(ds, cfg, dev):
 
 def compulsory_traffic(ds, dev):
     """Bytes the sweep HAS to move from HBM (measured on the device, outside the timed region): every 128-byte line
-    of the depth images and of the mask-word images that some point's gather touches, once (bff_diag_sweep_lines);
+    of the depth images and of the mask images (label bytes or words, segment by segment) that some point's gather touches, once (bff_diag_sweep_lines);
     the cloud once per tile of 8 frames (xyz stays in registers across a tile); the two counters read+written once.
     Re-fetches of a line by other waves (served by L2 / Infinity Cache or not) are what `traffic` has on top."""
     import ctypes
     n, hw = ds.n_points, ds.height * ds.width
     n_mviews = ds.view_mask_offs.shape[0] - 1
     maskbits = torch.empty((n_mviews, hw), device=dev, dtype=torch.int32 if ds.word_bits == 32 else torch.int64)
-    segmap = torch.empty((n_mviews, _lib.segmap_words(hw)), dtype=torch.int32, device=dev)
-    _lib.rle_to_maskbits(ds.run_start, ds.run_end, ds.mask_run_offs, ds.view_mask_offs, n_mviews, hw, ds.word_bits,
-                         maskbits, segmap)
-    del maskbits
+    labels = torch.empty((n_mviews, _lib.label_plane_stride(hw)), device=dev, dtype=torch.uint8)
+    segmap = torch.empty((n_mviews, 2 * _lib.segmap_words(hw)), dtype=torch.int32, device=dev)
+    _lib.rle_to_labels(ds.run_start, ds.run_end, ds.mask_run_offs, ds.view_mask_offs, n_mviews, hw, ds.word_bits,
+                       labels, maskbits, segmap)
+    del maskbits, labels
     line_words = (((hw + 15) // 16 + 31) // 32 + 1) // 2 * 2
     dl = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
     ml = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
+    ll = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
     k = (ctypes.c_double * 9)(*[float(v) for v in ds.cam_intr.reshape(-1)])
     _lib.call("bff_diag_sweep_lines", _lib._ptr(ds.xyz), n, ds.xyz.shape[1], _lib._ptr(ds.inv_pose), ctypes.cast(k, ctypes.c_void_p),
               ds.n_frames, _lib._ptr(ds.depth), _lib._ptr(ds.depth_index), ds.height, ds.width, 0.08, _lib._ptr(segmap),
-              ds.word_bits, _lib._ptr(ds.frame_mask), _lib._ptr(dl), _lib._ptr(ml), line_words)
+              ds.word_bits, _lib._ptr(ds.frame_mask), _lib._ptr(dl), _lib._ptr(ml), line_words, _lib._ptr(ll))
     count = lambda t: int(_lib.popcount_rows(t.view(torch.int64)).sum().item())
-    depth_lines, mask_lines = count(dl), count(ml)
+    depth_lines, mask_lines, label_lines = count(dl), count(ml), count(ll)
     tiles = (ds.n_frames + 7) // 8
     xyz_bytes, counter_bytes = 24 * n * tiles, 16 * n
-    return {"bytes": 128 * (depth_lines + mask_lines) + xyz_bytes + counter_bytes,
-            "depth_lines_128B": depth_lines, "mask_word_lines_128B": mask_lines, "xyz_bytes (once per 8-frame tile)": xyz_bytes,
+    return {"bytes": 128 * (depth_lines + mask_lines + label_lines) + xyz_bytes + counter_bytes,
+            "depth_lines_128B": depth_lines, "mask_word_lines_128B": mask_lines, "mask_label_lines_128B": label_lines, "xyz_bytes (once per 8-frame tile)": xyz_bytes,
             "counter_bytes": counter_bytes}
 
 

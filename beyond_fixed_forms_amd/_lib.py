@@ -22,7 +22,8 @@ _P, _I, _L, _D, _F = c_void_p, c_int32, c_int64, c_double, c_float
 # name -> argument ctypes (every entry point returns int); mirrors include/bff_hip.h one to one
 SIGNATURES = {
     "bff_rle_to_maskbits": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P],
-    "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P],
+    "bff_rle_to_labels": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P],
+    "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P],
     "bff_point_tile_bounds": [_P, _L, _L, _P, _P],
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
@@ -59,7 +60,7 @@ SIGNATURES = {
     "bff_clear_flagged_chunks_unless": [_P, _I, _L, _P, _P, _P],
     "bff_scene_project": [_P, _P, _P, _P],
     "bff_diag_gather": [_P, _L, _L, _P, _P],
-    "bff_diag_sweep_lines": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _I, _P, _P, _P, _L, _P],
+    "bff_diag_sweep_lines": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _I, _P, _P, _P, _L, _P, _P],
     "bff_scatter_bits": [_P, _I, _L, _P, _L, _L, _P, _P, _P],
     "bff_cross_popcount_dev": [_P, _I, _P, _I, _L, _P, _P, _I, _I, _P],
     "bff_cloud_layout": [_P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -68,14 +69,14 @@ SIGNATURES = {
     "bff_depth_from_u16": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P],
 }
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
-         "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
+         "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_label_plane_stride": (c_int64, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
          "bff_point_tile_size": (c_int32, []), "bff_merge_scratch_words": (c_int64, [c_int32]), "bff_merge_uses_chunk_bound": (c_int32, [c_int64]),
          "bff_profile_next_merge": (c_int32, [_P, _P]), "bff_group_slice_cap": (c_int32, [c_int32, c_int32]),
          "bff_resolve_overlaps_scratch_words": (c_int64, []), "bff_point_threshold_scratch_words": (c_int64, []), "bff_scene_header_words": (c_int32, [c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
          "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
          "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class BffLibraryError(RuntimeError):
@@ -177,15 +178,27 @@ def rle_to_maskbits(run_start, run_end, mask_run_offs, view_mask_offs, n_views, 
          _ptr(maskbits, torch.int32 if word_bits == 32 else torch.int64), _ptr(segmap, i32))
 
 
+def label_plane_stride(n_pixels):
+    return (n_pixels + 127) // 128 * 128
+
+
+def rle_to_labels(run_start, run_end, mask_run_offs, view_mask_offs, n_views, n_pixels, word_bits, labels, words, segmap):
+    """Segment-wise label bytes (uint8 [n_views][label_plane_stride(n_pixels)]) or mask words; segmap: int32
+    [n_views][2 * segmap_words(n_pixels)] (occupied | word form)."""
+    call("bff_rle_to_labels", _ptr(run_start, i32), _ptr(run_end, i32), _ptr(mask_run_offs, i32),
+         _ptr(view_mask_offs, i32), n_views, n_pixels, word_bits, _ptr(labels, u8),
+         _ptr(words, torch.int32 if word_bits == 32 else torch.int64), _ptr(segmap, i32))
+
+
 def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, height, width, depth_thresh,
                   maskbits, word_bits, frame_mask, frame_rowbase, frame_nmask, frame_flags,
-                  rows, masked_count, viewed_count, segmap=None, chunk_mask=None, tile_bounds=None):
+                  rows, masked_count, viewed_count, segmap=None, chunk_mask=None, tile_bounds=None, labels=None):
     k = (c_double * 9)(*[float(v) for v in cam_intr.reshape(-1)])
     n_frames = inv_pose.shape[0]
     nw = (n_points + 63) // 64
     call("bff_project_views", _ptr(xyz_soa, f64), n_points, xyz_soa.shape[1], _ptr(inv_pose, f64),
          ctypes.cast(k, c_void_p), n_frames, _ptr(depth, f32), _ptr(depth_index, i32), height, width,
-         float(depth_thresh), _ptr(maskbits), _ptr(segmap, i32), word_bits, _ptr(frame_mask, i32), _ptr(frame_rowbase, i32),
+         float(depth_thresh), _ptr(maskbits), _ptr(labels, u8), _ptr(segmap, i32), word_bits, _ptr(frame_mask, i32), _ptr(frame_rowbase, i32),
          _ptr(frame_nmask, i32), _ptr(frame_flags, i32), _ptr(rows, i64),
          0 if rows is None else rows.shape[0], nw, _ptr(chunk_mask, i64), _ptr(masked_count, i32),
          _ptr(viewed_count, i32), _ptr(tile_bounds, f64))

@@ -27,12 +27,13 @@ struct Intrinsics { double k[9]; };
 
 __device__ __forceinline__ void lds_phase_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <typename WordT>
+template <typename WordT, bool kLabels>
 __global__ __launch_bounds__(kBlock) void project_views_kernel(
     const double *__restrict__ xyz, int64_t n_points, int64_t n_pad,
     const double *__restrict__ inv_pose, Intrinsics K, int n_frames, int frames_per_block,
     const float *__restrict__ depth, const int32_t *__restrict__ depth_index, int H, int W, double thresh,
-    const WordT *__restrict__ maskbits, const uint32_t *__restrict__ segmap, int64_t seg_words,
+    const WordT *__restrict__ maskbits, const uint8_t *__restrict__ labels, int64_t label_stride,
+    const uint32_t *__restrict__ segmap, int64_t seg_words,
     const int32_t *__restrict__ frame_mask,
     const int32_t *__restrict__ frame_rowbase, const int32_t *__restrict__ frame_nmask,
     const int32_t *__restrict__ frame_flags,
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
         const int mi = maskbits ? frame_mask[f] : -1;
         const bool has_masks = mi >= 0;
         const WordT *mimg = has_masks ? maskbits + (int64_t)mi * hw : nullptr;
-        const uint32_t *smap = (segmap && has_masks) ? segmap + (int64_t)mi * seg_words : nullptr;
+        const uint8_t *limg = (kLabels && has_masks) ? labels + (int64_t)mi * label_stride : nullptr;   // wave-uniform
+        const uint32_t *smap = (segmap && has_masks) ? segmap + (int64_t)mi * seg_words * (kLabels ? 2 : 1) : nullptr;
         const int nm = has_masks ? frame_nmask[f] : 0;
         const bool count_viewed = (frame_flags[f] & 1) != 0;
         // Three phases per frame so that a thread's gathers are all in flight together (the sweep is bound by
@@ -135,24 +137,53 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
             pix[j] = inb ? (int)v * W + (int)u : -1;       // H*W < 2^31 (checked by the entry point)
         }
         float dval[kPPT];
-        uint32_t sbits[kPPT];
+        uint32_t sbits[kPPT], fbits[kPPT];                 // fbits (kLabels): segments in word form
 #pragma unroll
         for (int j = 0; j < kPPT; ++j) {
             dval[j] = 0.0f;
             sbits[j] = 0xffffffffu;
+            fbits[j] = 0xffffffffu;
             if (pix[j] >= 0) {
                 dval[j] = dimg[pix[j]];
                 // segments without any mask pixel were never written by the decoder: consult its bitmap
-                if (smap) sbits[j] = smap[pix[j] >> 12];
+                if (kLabels) {
+                    if (smap) {
+                        const uint2 sf = reinterpret_cast<const uint2 *>(smap)[pix[j] >> 12];
+                        sbits[j] = sf.x;
+                        fbits[j] = sf.y;
+                    }
+                } else if (smap) {
+                    sbits[j] = smap[pix[j] >> 12];
+                }
             }
         }
         bool vis[kPPT];
         WordT wv[kPPT];
+        if (kLabels) {
+            // segment by segment the decoder wrote either one label byte per pixel or the mask words (rle_to_maskbits_kernel
+            // <.., true>): one gather per point either way, both kinds in flight together
+            uint32_t lb[kPPT];
 #pragma unroll
-        for (int j = 0; j < kPPT; ++j) {
-            vis[j] = (pix[j] >= 0) && (dval[j] != 0.0f) && (fabs(cz[j] - (double)dval[j]) < thresh);
-            wv[j] = 0;
-            if (vis[j] && mimg && ((sbits[j] >> ((pix[j] >> 7) & 31)) & 1)) wv[j] = mimg[pix[j]];
+            for (int j = 0; j < kPPT; ++j) {
+                vis[j] = (pix[j] >= 0) && (dval[j] != 0.0f) && (fabs(cz[j] - (double)dval[j]) < thresh);
+                const int sb = (pix[j] >> 7) & 31;
+                const bool go = vis[j] && limg && ((sbits[j] >> sb) & 1);
+                const bool words = (fbits[j] >> sb) & 1;
+                lb[j] = 0;
+                wv[j] = 0;
+                if (go && !words) lb[j] = limg[pix[j]];
+                if (go && words) wv[j] = mimg[pix[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < kPPT; ++j)
+                if (lb[j]) wv[j] = (WordT)1 << ((lb[j] - 1) & (sizeof(WordT) * 8 - 1));
+        } else {
+#pragma unroll
+            for (int j = 0; j < kPPT; ++j) {
+                vis[j] = (pix[j] >= 0) && (dval[j] != 0.0f) && (fabs(cz[j] - (double)dval[j]) < thresh);
+                wv[j] = 0;
+                if (vis[j] && mimg && ((sbits[j] >> ((pix[j] >> 7) & 31)) & 1)) wv[j] = mimg[pix[j]];
+            }
         }
         WordT present = 0;
 #pragma unroll
@@ -215,7 +246,8 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
 
 // Measurement aid: which 128-byte lines of the depth images and of the mask-word images does one sweep touch?
 // One thread per (frame, point) recomputes the pixel with the sweep's own arithmetic and marks bit (pixel / ppl) of the
-// frame's bitmap (ppl = pixels per 128-B line: 32 for float depth and 32-bit mask words, 16 for 64-bit words); the
+// frame's bitmap (ppl = pixels per 128-B line: 32 for float depth and 32-bit mask words, 16 for 64-bit words; with
+// label_lines the segment bitmap is bff_rle_to_labels' and segments in label form mark that bitmap, 128 pixels per line); the
 // caller counts the bits.  The COMPULSORY HBM traffic of the sweep is 128 B per marked line (each line has to come
 // in at least once; everything beyond that is re-fetching), plus the cloud once per frame tile and the counters.
 template <typename WordT>
@@ -224,7 +256,7 @@ __global__ void sweep_lines_kernel(const double *__restrict__ xyz, int64_t n_poi
                                    const float *__restrict__ depth, const int32_t *__restrict__ depth_index, int H, int W,
                                    double thresh, const uint32_t *__restrict__ segmap, int64_t seg_words,
                                    const int32_t *__restrict__ frame_mask, uint32_t *__restrict__ depth_lines,
-                                   uint32_t *__restrict__ mask_lines, int64_t line_words)
+                                   uint32_t *__restrict__ mask_lines, int64_t line_words, uint32_t *__restrict__ label_lines)
 {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int f = blockIdx.y;
@@ -244,7 +276,15 @@ __global__ void sweep_lines_kernel(const double *__restrict__ xyz, int64_t n_poi
     const float d = depth[(int64_t)depth_index[f] * H * W + pix];
     const int mi = frame_mask ? frame_mask[f] : -1;
     if (mi < 0 || d == 0.0f || !(fabs(cz - (double)d) < thresh)) return;
-    if (segmap && !((segmap[(int64_t)mi * seg_words + (pix >> 12)] >> ((pix >> 7) & 31)) & 1)) return;
+    if (label_lines) {
+        const uint32_t *sm = segmap + 2 * ((int64_t)mi * seg_words + (pix >> 12));
+        if (!((sm[0] >> ((pix >> 7) & 31)) & 1)) return;
+        if (!((sm[1] >> ((pix >> 7) & 31)) & 1)) {                      // label form: 128 pixels per line
+            const int ll = pix >> 7;
+            atomicOr(label_lines + (int64_t)f * line_words + (ll >> 5), 1u << (ll & 31));
+            return;
+        }
+    } else if (segmap && !((segmap[(int64_t)mi * seg_words + (pix >> 12)] >> ((pix >> 7) & 31)) & 1)) return;
     const int ml = pix / (int)(128 / sizeof(WordT));
     atomicOr(mask_lines + (int64_t)f * line_words + (ml >> 5), 1u << (ml & 31));
 }
@@ -315,11 +355,20 @@ __device__ __forceinline__ uint64_t wave_xor_scan(uint64_t v)
     return (uint64_t)wave_xor_scan((uint32_t)v) | ((uint64_t)wave_xor_scan((uint32_t)(v >> 32)) << 32);
 }
 
-template <typename WordT>
+// kLabels: every 128-pixel segment is written in ONE of two forms, chosen here segment by segment:
+//   label form  one BYTE per pixel in `labels` -- 0 = no mask, b in 1..64 = exactly mask b - 1 -- when no pixel of the
+//               segment lies in two masks (the segment is one 128-byte line of the label plane);
+//   word form   the mask words in `maskbits`, as without labels, when some pixel does.
+// The segment bitmap then has TWO uint32 per 4096 pixels: [2k] = segment holds a mask pixel, [2k + 1] = segment is in
+// word form.  Masks of one view overlap on few pixels in real data (one mask per detected box), so most segments cost a
+// quarter (32 masks) or an eighth (64 masks) of the bytes to write -- the decoder is bound by its writes -- and to
+// gather; where masks do overlap nothing is lost against the plain word image, and the sweep never chases a pointer.
+template <typename WordT, bool kLabels>
 __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
     const int32_t *__restrict__ run_start, const int32_t *__restrict__ run_end,
     const int32_t *__restrict__ mask_run_offs, const int32_t *__restrict__ view_mask_offs,
-    int64_t n_pixels, WordT *__restrict__ maskbits, uint32_t *__restrict__ segmap, int64_t seg_words)
+    int64_t n_pixels, WordT *__restrict__ maskbits, uint32_t *__restrict__ segmap, int64_t seg_words,
+    uint8_t *__restrict__ labels, int64_t label_stride)
 {
     __shared__ WordT lds[kBlock / kWave][kWaveChunk];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -355,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
         for (int k = 0; k < kQ; ++k) bits[h * kHalf + lane * kQ + k] = 0;
     lds_phase_fence();
     const WordT bit = (WordT)1 << (lane & (int)(sizeof(WordT) * 8 - 1));
-    uint32_t *smap = segmap ? segmap + (int64_t)v * seg_words : nullptr;
+    uint32_t *smap = segmap ? segmap + (int64_t)v * seg_words * (kLabels ? 2 : 1) : nullptr;
     for (int c = 0; c < kWaveChunks; ++c) {
         const int c0 = band0 + c * kWaveChunk;        // scalar
         if (c0 >= npx) break;
@@ -391,7 +440,9 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
         WordT carry_in = 0;                                          // XOR of the sub-blocks before this one
         using Vec = __attribute__((ext_vector_type(4))) uint32_t;
         WordT *img_c = img + c0;                                     // scalar base; the lane offset never changes
+        uint8_t *lab_c = kLabels ? labels + (int64_t)v * label_stride + c0 : nullptr;
         uint32_t seg_bits = 0;                                       // scalar: non-zero 128-pixel segments of the chunk
+        uint32_t fmt_bits = 0;                                       // scalar (kLabels): segments written in word form
 #pragma unroll
         for (int h = 0; h < kSub; ++h) {
             const WordT incl = wave_xor_scan(tot[h]);
@@ -411,7 +462,33 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
                 store = (lane < 32 ? lo : up) != 0;
             }
             const int q = h * kHalf + lane * kQ;                     // word of the chunk
-            if (store) {
+            bool as_labels = false;
+            if (kLabels) {
+                static_assert(kQ == 4, "a lane's labels are one 32-bit store");
+                uint32_t packed = 0;
+                bool several = false;
+#pragma unroll
+                for (int k = 0; k < kQ; ++k) {
+                    const WordT w = outv[k];
+                    several |= (w & (w - 1)) != 0;
+                    const int first = (sizeof(WordT) == 8) ? __ffsll((unsigned long long)w) : __ffs((unsigned)w);   // 0 when empty
+                    packed |= (uint32_t)first << (8 * k);
+                }
+                const uint64_t sv = __ballot(several);
+                const uint32_t slo = (uint32_t)sv, sup = (uint32_t)(sv >> 32);
+                fmt_bits |= ((slo ? 1u : 0u) | (sup ? 2u : 0u)) << (2 * h);
+                as_labels = (lane < 32 ? slo : sup) == 0;
+                if (store && as_labels) {
+                    if (whole || c0 + q + kQ <= c1) {                // label_stride and chunk starts are multiples of 4
+                        *reinterpret_cast<uint32_t *>(lab_c + q) = packed;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < kQ; ++k)
+                            if (c0 + q + k < c1) lab_c[q + k] = (uint8_t)(packed >> (8 * k));
+                    }
+                }
+            }
+            if (store && !as_labels) {
                 if (whole || c0 + q + kQ <= c1) {     // `whole` is scalar: the common case has no per-lane bounds test
                     const Vec *src = reinterpret_cast<const Vec *>(outv);
                     Vec *dst = reinterpret_cast<Vec *>(img_c + q);             // chunk starts are multiples of 1024 words
@@ -425,7 +502,14 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
             }
         }
         // a chunk's 8 segments are 8 consecutive bits of one bitmap word (chunks start at multiples of 1024 pixels)
-        if (smap && seg_bits && lane == 0) atomicOr(smap + (c0 >> 12), seg_bits << ((c0 >> 7) & 31));
+        if (smap && seg_bits && lane == 0) {
+            if (kLabels) {
+                atomicOr(smap + 2 * (c0 >> 12), seg_bits << ((c0 >> 7) & 31));
+                if (fmt_bits) atomicOr(smap + 2 * (c0 >> 12) + 1, fmt_bits << ((c0 >> 7) & 31));
+            } else {
+                atomicOr(smap + (c0 >> 12), seg_bits << ((c0 >> 7) & 31));
+            }
+        }
     }
 }
 
@@ -464,9 +548,32 @@ extern "C" int bff_event_elapsed_ms(void *start_event, void *stop_event, float *
     return e == hipSuccess ? BFF_OK : fail((int)e, "bff_event_elapsed_ms: %s", hipGetErrorString(e));
 }
 
+extern "C" int64_t bff_label_plane_stride(int64_t n_pixels) { return ceil_div(n_pixels, 128) * 128; }
+
+static int rle_decode(const int32_t *run_start, const int32_t *run_end, const int32_t *mask_run_offs,
+                      const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels,
+                      int32_t word_bits, void *maskbits, uint32_t *segmap, uint8_t *labels, void *stream);
+
 extern "C" int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const int32_t *mask_run_offs,
                                    const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels,
                                    int32_t word_bits, void *maskbits, uint32_t *segmap, void *stream)
+{
+    return rle_decode(run_start, run_end, mask_run_offs, view_mask_offs, n_views, n_pixels, word_bits, maskbits, segmap,
+                      nullptr, stream);
+}
+
+extern "C" int bff_rle_to_labels(const int32_t *run_start, const int32_t *run_end, const int32_t *mask_run_offs,
+                                 const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels,
+                                 int32_t word_bits, uint8_t *labels, void *words, uint32_t *segmap, void *stream)
+{
+    BFF_REQUIRE(labels && (words || n_views == 0), "bff_rle_to_labels: null pointer");
+    return rle_decode(run_start, run_end, mask_run_offs, view_mask_offs, n_views, n_pixels, word_bits, words, segmap,
+                      labels, stream);
+}
+
+static int rle_decode(const int32_t *run_start, const int32_t *run_end, const int32_t *mask_run_offs,
+                      const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels,
+                      int32_t word_bits, void *maskbits, uint32_t *segmap, uint8_t *labels, void *stream)
 {
     BFF_REQUIRE(n_views >= 0 && n_pixels > 0, "bff_rle_to_maskbits: bad sizes");
     BFF_REQUIRE(word_bits == 32 || word_bits == 64, "bff_rle_to_maskbits: word_bits must be 32 or 64");
@@ -475,16 +582,26 @@ extern "C" int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_
     BFF_REQUIRE(mask_run_offs && view_mask_offs && maskbits, "bff_rle_to_maskbits: null pointer");   // run arrays may be empty (NULL)
     dim3 grid((unsigned)ceil_div(n_pixels, (int64_t)kWaveChunk * kWaveChunks * (kBlock / kWave)), (unsigned)n_views);
     const int64_t seg_words = ceil_div(ceil_div(n_pixels, 128), 32);
+    BFF_REQUIRE(!labels || segmap, "bff_rle_to_labels: the label plane needs its segment bitmap");
     if (segmap) {
-        hipError_t e = hipMemsetAsync(segmap, 0, sizeof(uint32_t) * (size_t)n_views * seg_words, as_stream(stream));
+        hipError_t e = hipMemsetAsync(segmap, 0, sizeof(uint32_t) * (size_t)n_views * seg_words * (labels ? 2 : 1),
+                                      as_stream(stream));
         if (e != hipSuccess) return fail((int)e, "bff_rle_to_maskbits: memset: %s", hipGetErrorString(e));
     }
-    if (word_bits == 32)
-        rle_to_maskbits_kernel<uint32_t><<<grid, kBlock, 0, as_stream(stream)>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words);
+    const int64_t ls = bff_label_plane_stride(n_pixels);
+    hipStream_t st = as_stream(stream);
+    if (word_bits == 32 && !labels)
+        rle_to_maskbits_kernel<uint32_t, false><<<grid, kBlock, 0, st>>>(
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words, nullptr, 0);
+    else if (word_bits == 32)
+        rle_to_maskbits_kernel<uint32_t, true><<<grid, kBlock, 0, st>>>(
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words, labels, ls);
+    else if (!labels)
+        rle_to_maskbits_kernel<uint64_t, false><<<grid, kBlock, 0, st>>>(
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words, nullptr, 0);
     else
-        rle_to_maskbits_kernel<uint64_t><<<grid, kBlock, 0, as_stream(stream)>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words);
+        rle_to_maskbits_kernel<uint64_t, true><<<grid, kBlock, 0, st>>>(
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words, labels, ls);
     return launched("bff_rle_to_maskbits");
 }
 
@@ -492,7 +609,7 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
                                  const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
                                  const float *depth, const int32_t *depth_index, int32_t height, int32_t width,
                                  double depth_thresh,
-                                 const void *maskbits, const uint32_t *segmap, int32_t word_bits,
+                                 const void *maskbits, const uint8_t *labels, const uint32_t *segmap, int32_t word_bits,
                                  const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
                                  const int32_t *frame_flags,
                                  uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
@@ -517,18 +634,18 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
     fpb = fpb < 1 ? 1 : (fpb > 8 ? 8 : fpb);
     dim3 grid((unsigned)gx, (unsigned)ceil_div(n_frames, fpb));
     const int64_t seg_words = ceil_div(ceil_div((int64_t)height * width, 128), 32);
+    const int64_t label_stride = bff_label_plane_stride((int64_t)height * width);
+    BFF_REQUIRE(!labels || (maskbits && segmap), "bff_project_views: a label plane comes with its word plane and segment bitmap");
     const hipEvent_t ev0 = g_sweep_start, ev1 = g_sweep_stop;   // attached to the dispatch itself when set
     g_sweep_start = g_sweep_stop = nullptr;
-    if (!maskbits || word_bits == 32)
-        hipExtLaunchKernelGGL(project_views_kernel<uint32_t>, grid, dim3(kBlock), 0, as_stream(stream), ev0, ev1, 0,
-            xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
-            (const uint32_t *)maskbits, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
-            chunk_mask, mw, masked_count, viewed_count, tile_bounds);
-    else
-        hipExtLaunchKernelGGL(project_views_kernel<uint64_t>, grid, dim3(kBlock), 0, as_stream(stream), ev0, ev1, 0,
-            xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,
-            (const uint64_t *)maskbits, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask, frame_flags, rows, nw,
-            chunk_mask, mw, masked_count, viewed_count, tile_bounds);
+#define BFF_SWEEP(WORD, LAB)                                                                                            \
+    hipExtLaunchKernelGGL((project_views_kernel<WORD, LAB>), grid, dim3(kBlock), 0, as_stream(stream), ev0, ev1, 0, xyz,  \
+        n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,                   \
+        (const WORD *)maskbits, labels, label_stride, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask,        \
+        frame_flags, rows, nw, chunk_mask, mw, masked_count, viewed_count, tile_bounds)
+    if (!maskbits || word_bits == 32) { if (labels) BFF_SWEEP(uint32_t, true); else BFF_SWEEP(uint32_t, false); }
+    else { if (labels) BFF_SWEEP(uint64_t, true); else BFF_SWEEP(uint64_t, false); }
+#undef BFF_SWEEP
     return launched("bff_project_views");
 }
 
@@ -551,10 +668,12 @@ extern "C" int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t
                                     const double *cam_intr_host, int32_t n_frames, const float *depth,
                                     const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
                                     const uint32_t *segmap, int32_t word_bits, const int32_t *frame_mask,
-                                    uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words, void *stream)
+                                    uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words,
+                                    uint32_t *label_lines, void *stream)
 {
     BFF_REQUIRE(xyz && inv_pose && cam_intr_host && depth && depth_index && depth_lines && mask_lines && n_points > 0 &&
                 n_frames > 0 && (word_bits == 32 || word_bits == 64), "bff_diag_sweep_lines: bad arguments");
+    BFF_REQUIRE(!label_lines || segmap, "bff_diag_sweep_lines: label lines need the label segment bitmap");
     BFF_LIMIT(n_frames <= 65535, "bff_diag_sweep_lines: too many frames");
     Intrinsics K;
     for (int i = 0; i < 9; ++i) K.k[i] = cam_intr_host[i];
@@ -562,9 +681,11 @@ extern "C" int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t
     dim3 grid((unsigned)ceil_div(n_points, 256), (unsigned)n_frames);
     if (word_bits == 32)
         sweep_lines_kernel<uint32_t><<<grid, 256, 0, as_stream(stream)>>>(xyz, n_points, n_pad, inv_pose, K, n_frames, depth,
-            depth_index, height, width, depth_thresh, segmap, seg_words, frame_mask, depth_lines, mask_lines, line_words);
+            depth_index, height, width, depth_thresh, segmap, seg_words, frame_mask, depth_lines, mask_lines, line_words,
+            label_lines);
     else
         sweep_lines_kernel<uint64_t><<<grid, 256, 0, as_stream(stream)>>>(xyz, n_points, n_pad, inv_pose, K, n_frames, depth,
-            depth_index, height, width, depth_thresh, segmap, seg_words, frame_mask, depth_lines, mask_lines, line_words);
+            depth_index, height, width, depth_thresh, segmap, seg_words, frame_mask, depth_lines, mask_lines, line_words,
+            label_lines);
     return launched("bff_diag_sweep_lines");
 }

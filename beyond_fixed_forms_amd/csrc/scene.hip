@@ -58,9 +58,9 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
 #define BFF_ZERO(ptr, bytes) do { e = hipMemsetAsync((ptr), 0, (bytes), st); \
         if (e != hipSuccess) return fail((int)e, "bff_scene_project: memset: %s", hipGetErrorString(e)); } while (0)
 
-    // a1: 2-D RLE -> mask words (+ segment bitmap)
-    BFF_TRY(bff_rle_to_maskbits(sc->run_start, sc->run_end, sc->mask_run_offs, sc->view_mask_offs, sc->n_mviews, hw,
-                                sc->word_bits, ws->maskbits, ws->segmap, stream));
+    // a1: 2-D RLE -> label plane (+ words where masks overlap, + segment bitmap)
+    BFF_TRY(bff_rle_to_labels(sc->run_start, sc->run_end, sc->mask_run_offs, sc->view_mask_offs, sc->n_mviews, hw,
+                              sc->word_bits, ws->labels, ws->maskbits, ws->segmap, stream));
     // a2-a8 (+a15): the fused sweep.  ws->rows is all zero on entry (and again on exit, see below); the counters,
     // the group counters and the chunk flags are one block, cleared by one fill
     const bool ratio = pr->filter_mode == 2;
@@ -70,7 +70,7 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     BFF_ZERO(ws->masked, ws->zero_bytes);
     BFF_ZERO(hdr, sizeof(int32_t) * BFF_HDR_SIZES);
     BFF_TRY(bff_project_views(sc->xyz, n, sc->n_pad, sc->inv_pose, sc->cam_intr, sc->n_frames, sc->depth, sc->depth_index,
-                              sc->height, sc->width, pr->depth_thresh, ws->maskbits, ws->segmap, sc->word_bits,
+                              sc->height, sc->width, pr->depth_thresh, ws->maskbits, ws->labels, ws->segmap, sc->word_bits,
                               sc->frame_mask, sc->frame_rowbase, sc->frame_nmask, sc->frame_flags, ws->rows, n_rows, nw,
                               ws->chunk_mask, ws->masked, ratio ? ws->viewed : nullptr, sc->tile_bounds, stream));
     // a14 / a15: point filter, threshold stays on the device (header words 2, 3 = n_unique, thr)

@@ -40,7 +40,7 @@ class ParamsStruct(ctypes.Structure):
                 ("min_members", c_int32), ("filter_mode", c_int32), ("filter_sort", c_int32)]
 
 
-_WS_PTRS = ["maskbits", "segmap", "rows", "chunk_mask", "keep", "tile_mask", "agg", "both",
+_WS_PTRS = ["maskbits", "segmap", "labels", "rows", "chunk_mask", "keep", "tile_mask", "agg", "both",
             "masked", "viewed", "sel_scratch", "area", "mean_word", "order", "parent", "comp", "count",
             "gmembers", "goffs", "slices", "inter", "pair_masks", "pair_scratch", "vals", "vals_sorted", "hist", "merge_scratch", "chunk_pop",
             "sig", "sig_keys", "sig_sorted", "sort_temp"]
@@ -153,7 +153,8 @@ class SceneWorkspace:
         nt = (n_rows + 63) // 64
         i32, i64, f32 = torch.int32, torch.int64, torch.float32
         self._need("maskbits", n_mviews * hw * (1 if ds.word_bits == 32 else 2), i32)
-        self._need("segmap", n_mviews * _lib.segmap_words(hw), i32)
+        self._need("segmap", 2 * n_mviews * _lib.segmap_words(hw), i32)      # two words per 32 segments: occupied | word form
+        self._need("labels", n_mviews * int(lib.bff_label_plane_stride(hw)), torch.uint8)
         if self._need("rows", n_rows * nw, i64, zero=True):
             self.rows_dirty = False
         # masked | viewed | count | chunk_mask: one allocation, cleared by one fill per scene

@@ -32,7 +32,7 @@ extern "C" {
 #define BFF_E_ARG (-1)      /* null pointer / negative size / unsupported parameter */
 #define BFF_E_LIMIT (-2)    /* size beyond what a kernel supports (documented per call) */
 
-#define BFF_ABI_VERSION 3
+#define BFF_ABI_VERSION 4
 
 int bff_abi_version(void);
 const char *bff_last_error(void);
@@ -66,6 +66,20 @@ int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const 
                         const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels, int32_t word_bits,
                         void *maskbits, uint32_t *segmap, void *stream);
 
+/* The same decode, each 128-pixel segment written in the cheaper of two forms:
+ *   label form  labels[v][p] (uint8, rows of bff_label_plane_stride(n_pixels) bytes) = 0 when pixel p of view v lies in
+ *               no mask, b + 1 when it lies in mask view_mask_offs[v] + b -- when no pixel of the segment lies in two masks;
+ *   word form   words[v][p] = the word of bff_rle_to_maskbits (same layout, same word_bits) -- when some pixel does.
+ * segmap (required): uint32 [n_views][2 * ceil(ceil(n_pixels/128)/32)]: word 2k = "segment holds a mask pixel" for
+ * segments 32k..32k+31 (others are not written at all), word 2k + 1 = "segment is in word form".  Only the plane a
+ * segment's form names is written for it.  Masks of one view overlap on few pixels (one mask per detected box): the
+ * decoder -- bound by its writes -- stores, and the sweep gathers from, a quarter (word_bits 32) or an eighth (64) of
+ * the bytes, and a label segment is one 128-byte line.  labels must be 4-byte aligned, segmap 8-byte aligned. */
+int64_t bff_label_plane_stride(int64_t n_pixels);
+int bff_rle_to_labels(const int32_t *run_start, const int32_t *run_end, const int32_t *mask_run_offs,
+                      const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels, int32_t word_bits,
+                      uint8_t *labels, void *words, uint32_t *segmap, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * a2-a7 (+a15) -- fused per-frame: world->camera transform, projection, rounding, bounds +
  * depth test, mask-word gather, instance bit rows and the two per-point vote counters.
@@ -78,6 +92,8 @@ int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const 
  *   inv_pose     float64 [n_frames][16] row-major inverse camera pose (np.linalg.inv on the host)
  *   cam_intr     float64 [9] row-major K (HOST pointer; copied into kernel arguments)
  *   depth        float32 [n_depth][H*W] metres; frame f uses image depth_index[f]
+ *   maskbits     mask words of bff_rle_to_maskbits, or -- with `labels` -- the word plane of bff_rle_to_labels
+ *   labels       label plane of bff_rle_to_labels (then maskbits and segmap are its companions) or NULL
  *   segmap       the decoder's segment bitmap (see bff_rle_to_maskbits) or NULL
  *   frame_mask   int32 [n_frames]: index of the frame's mask-word image in `maskbits`, or -1
  *   frame_rowbase int32 [n_frames]: first instance row of the frame (row = rowbase + bit)
@@ -105,7 +121,7 @@ int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
                       const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
                       const float *depth, const int32_t *depth_index, int32_t height, int32_t width,
                       double depth_thresh,
-                      const void *maskbits, const uint32_t *segmap, int32_t word_bits,
+                      const void *maskbits, const uint8_t *labels, const uint32_t *segmap, int32_t word_bits,
                       const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
                       const int32_t *frame_flags,
                       uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
@@ -462,7 +478,8 @@ typedef struct bff_scene_params {
  * masked, viewed, count and chunk_mask must be ONE allocation in this order (`zero_bytes` bytes from `masked`): the call
  * clears them with a single fill. */
 typedef struct bff_scene_workspace {
-    void *maskbits; uint32_t *segmap;
+    void *maskbits; uint32_t *segmap;  /* word plane and two-word segment bitmap of bff_rle_to_labels */
+    uint8_t *labels;                /* [n_mviews][bff_label_plane_stride(H*W)] */
     uint64_t *rows, *chunk_mask, *keep, *tile_mask, *agg, *both;
     int32_t *masked, *viewed, *sel_scratch, *area, *mean_word, *order, *parent, *comp, *count;
     int32_t *gmembers, *goffs, *slices, *inter;
@@ -515,12 +532,13 @@ int bff_cloud_layout(const double *pts, int64_t n, int64_t stride, int64_t n_pad
 
 /* Measurement aid: the 128-byte lines of the depth and mask-word images that one sweep touches, as bitmaps (uint32
  * [n_frames][line_words], zeroed by the caller; line index = pixel / (pixels per 128 B)).  128 B per marked line is
- * the sweep's compulsory HBM traffic for these images (bench.py: roofline.compulsory). */
+ * the sweep's compulsory HBM traffic for these images (bench.py: roofline.compulsory).  label_lines != NULL: segmap is
+ * bff_rle_to_labels' two-word bitmap; segments in label form mark label_lines (128 pixels per line) instead. */
 int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
                          const double *cam_intr_host, int32_t n_frames, const float *depth, const int32_t *depth_index,
                          int32_t height, int32_t width, double depth_thresh, const uint32_t *segmap, int32_t word_bits,
                          const int32_t *frame_mask, uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words,
-                         void *stream);
+                         uint32_t *label_lines, void *stream);
 /* Measurement aid: n_lanes lanes each read one float at element lane * stride of src (every element once per launch)
  * -- a gather with a known number of distinct cache lines, to calibrate the FETCH_SIZE counter (scripts/diag_membw.py). */
 int bff_diag_gather(const float *src, int64_t n_lanes, int64_t stride, float *out, void *stream);

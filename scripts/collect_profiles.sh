@@ -1,27 +1,55 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of one code state on the GPU box (run from the repo root):
-#   bash scripts/collect_profiles.sh gpurun_out/profiles_new
-# kernel stats + trace summary, separate FETCH_SIZE / WRITE_SIZE counter passes, the bench lines of the same
-# build, the strictly sequential step timeline and the pipelined occupancy.  Raw traces stay under /tmp.
+#   bash scripts/collect_profiles.sh gpurun_out/profiles_new [parts]
+# parts (default: all of them; one gpurun call is limited to 20 minutes, so they can be run apart):
+#   stats  kernel stats + trace summary of the bench command, pipelined occupancy
+#   seq    strictly sequential step timeline
+#   pmc2   separate FETCH_SIZE / WRITE_SIZE counter passes, config 2        pmc4   the same for config 4
+#   cal    FETCH_SIZE on access patterns with a known number of distinct lines (scripts/diag_membw.py)
+#   bench  the bench lines of the same build
+# Counter passes collect only this library's kernels (--kernel-include-regex): the synthetic scene generator issues
+# ~10^5 torch kernels before the timed region.  Every pass is summarised as soon as it ends; raw traces stay in /tmp.
 set -o pipefail
 OUT=${1:-gpurun_out/profiles_new}
+PARTS=${2:-"stats seq pmc2 pmc4 cal bench"}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 RAW=/tmp/bff_prof
-rm -rf $RAW
+rm -rf $RAW $RAW.*
 B="python3 bench.py --no-cpu-baseline"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -- $B --steps 10 --warmup 2 > $RAW.stats.log 2>&1 || { tail -5 $RAW.stats.log; exit 1; }
-tail -1 $RAW.stats.log > "$OUT/bench_c2_under_rocprof.json"
-python3 scripts/pipeline_occupancy.py $RAW/stats 8 > "$OUT/pipeline_occupancy.txt"
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $RAW/seq -- $B --steps 6 --warmup 2 --no-pipeline > $RAW.seq.log 2>&1 || { tail -5 $RAW.seq.log; exit 1; }
-python3 scripts/step_timeline.py $RAW/seq > "$OUT/step_timeline_no_pipeline.txt"
-rm -rf $RAW/seq
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $RAW/pmc_fetch -- $B --steps 4 --warmup 1 --no-pipeline > $RAW.f.log 2>&1 || { tail -5 $RAW.f.log; exit 1; }
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $RAW/pmc_write -- $B --steps 4 --warmup 1 --no-pipeline > $RAW.w.log 2>&1 || { tail -5 $RAW.w.log; exit 1; }
-python3 scripts/prof_summarize.py $RAW "$OUT"
-echo "profiles done"
-for s in c2 c1 c4 c5; do timeout -k 10 300 $B --shape $s 2>/dev/null | tail -1 > "$OUT/bench_$s.json"; done
-timeout -k 10 300 $B --no-pipeline 2>/dev/null | tail -1 > "$OUT/bench_c2_no_pipeline.json"
-timeout -k 10 300 $B --shape c4 --no-pipeline 2>/dev/null | tail -1 > "$OUT/bench_c4_no_pipeline.json"
-timeout -k 10 600 python3 bench.py 2>/dev/null | tail -1 > "$OUT/bench_c2_with_cpu_baseline.json"
+INC="--kernel-include-regex bff|gather_stride"
+run() { local tag=$1; shift; timeout -k 10 500 "$@" > $RAW.$tag.log 2>&1 || { echo "FAILED: $tag"; tail -5 $RAW.$tag.log; exit 1; }; echo "done: $tag ($SECONDS s)"; }
+summarize() { python3 scripts/prof_summarize.py $RAW "$OUT" ${1:-bff} > /dev/null && rm -rf $RAW; }
+for part in $PARTS; do case $part in
+stats)
+    run stats rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -- $B --steps 12 --warmup 4
+    tail -1 $RAW.stats.log > "$OUT/bench_c2_under_rocprof.json"
+    python3 scripts/pipeline_occupancy.py $RAW/stats 8 > "$OUT/pipeline_occupancy.txt"
+    summarize ;;
+seq)
+    run seq rocprofv3 --kernel-trace --output-format csv -d $RAW/seq -- $B --steps 8 --warmup 4 --no-pipeline
+    python3 scripts/step_timeline.py $RAW/seq 4 > "$OUT/step_timeline_no_pipeline.txt"
+    rm -rf $RAW ;;
+pmc2)
+    run pmc_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace $INC --output-format csv -d $RAW/pmc_fetch -- $B --steps 8 --warmup 4 --no-pipeline
+    summarize
+    run pmc_write rocprofv3 --pmc WRITE_SIZE --kernel-trace $INC --output-format csv -d $RAW/pmc_write -- $B --steps 8 --warmup 4 --no-pipeline
+    summarize ;;
+pmc4)
+    run pmc_fetch_c4 rocprofv3 --pmc FETCH_SIZE --kernel-trace $INC --output-format csv -d $RAW/pmc_fetch_c4 -- $B --shape c4 --scenes 2 --steps 4 --warmup 2 --no-pipeline
+    summarize
+    run pmc_write_c4 rocprofv3 --pmc WRITE_SIZE --kernel-trace $INC --output-format csv -d $RAW/pmc_write_c4 -- $B --shape c4 --scenes 2 --steps 4 --warmup 2 --no-pipeline
+    summarize ;;
+cal)
+    run cal_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace $INC --output-format csv -d $RAW/cal_fetch -- python3 scripts/diag_membw.py
+    cp $RAW.cal_fetch.log "$OUT/gather_calibration_stdout.txt"
+    summarize gather_stride ;;
+bench)
+    for s in c2 c1 c4 c5; do timeout -k 10 300 $B --shape $s 2>/dev/null | tail -1 > "$OUT/bench_$s.json"; done
+    timeout -k 10 300 $B --no-pipeline 2>/dev/null | tail -1 > "$OUT/bench_c2_no_pipeline.json"
+    timeout -k 10 300 $B --shape c4 --no-pipeline 2>/dev/null | tail -1 > "$OUT/bench_c4_no_pipeline.json"
+    timeout -k 10 300 $B --include-upload 2>/dev/null | tail -1 > "$OUT/bench_c2_include_upload.json"
+    timeout -k 10 600 python3 bench.py 2>/dev/null | tail -1 > "$OUT/bench_c2_with_cpu_baseline.json"
+    echo "done: bench ($SECONDS s)" ;;
+esac; done
 ls -la "$OUT"

@@ -15,6 +15,9 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    if name.startswith("void "):
+        name = name[5:]
     return name.split("(")[0][:110]
 
 

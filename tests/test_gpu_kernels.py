@@ -63,6 +63,31 @@ def maskbits_from_dense(lib, masks_list, hw):
     assert np.array_equal(out2.cpu().numpy()[per_px], full[per_px]) and (out2.cpu().numpy()[~per_px] == -1).all()
     maskbits_from_dense.last_segmap = seg
     maskbits_from_dense.last_sparse = out2
+    # label / word segments: a 128-pixel segment without a pixel in two masks is written as one byte per pixel (0 none,
+    # b + 1 = mask b) into the label plane, any other as words into the word plane; nothing else is written
+    ls = lib.label_plane_stride(hw)
+    assert ls == lib.load().bff_label_plane_stride(hw) and ls % 128 == 0 and 0 <= ls - hw < 128
+    lab = torch.full((len(masks_list), ls), 0xEE, dtype=torch.uint8, device=DEV)
+    ovf = torch.full_like(out, -1)
+    seg3 = torch.empty((len(masks_list), 2 * lib.segmap_words(hw)), dtype=torch.int32, device=DEV)
+    lib.rle_to_labels(t(rs), t(re), t(offs), t(voffs), len(masks_list), hw, wb, lab, ovf, seg3)
+    assert torch.equal(seg3[:, 0::2], seg)
+    fu = full.astype(np.uint64 if wb == 64 else np.uint32).astype(np.uint64)
+    several = (fu & (fu - np.uint64(1))) != 0
+    low = fu & (~fu + np.uint64(1))                                    # lowest set bit
+    first = np.where(fu != 0, np.log2(np.maximum(low, 1).astype(np.float64)).astype(np.int64) + 1, 0).astype(np.uint8)
+    n_seg = (hw + 127) // 128
+    seg_several = np.stack([np.add.reduceat(several[v].astype(np.int64), np.arange(0, hw, 128)) > 0 for v in range(len(masks_list))])
+    fmt = np.unpackbits(seg3[:, 1::2].contiguous().cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[:, :n_seg].astype(bool)
+    assert np.array_equal(fmt, seg_several)
+    as_words = np.repeat(fmt, 128, axis=1)[:, :hw]
+    got_lab, got_ovf = lab.cpu().numpy(), ovf.cpu().numpy()
+    in_lab = per_px & ~as_words
+    assert np.array_equal(got_lab[:, :hw][in_lab], first[in_lab]) and (got_lab[:, :hw][~in_lab] == 0xEE).all()
+    assert (got_lab[:, hw:] == 0xEE).all()
+    assert np.array_equal(got_ovf[as_words], full[as_words]) and (got_ovf[~as_words] == -1).all()
+    maskbits_from_dense.last_labels_segmap = seg3
+    maskbits_from_dense.last_labels = (lab, ovf)
     return out, wb
 
 
@@ -131,6 +156,12 @@ def run_view(lib, xyz, inv_pose, k33, depth, masks):
     lib.project_views(*args, maskbits_from_dense.last_sparse, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows2, mc2, vc2,
                       segmap=maskbits_from_dense.last_segmap)
     assert torch.equal(rows2, rows) and torch.equal(mc2, mc) and torch.equal(vc2, vc)
+    # same sweep through the label / word segments
+    lab, ovf = maskbits_from_dense.last_labels
+    rows4, mc4, vc4 = torch.zeros_like(rows), torch.zeros_like(mc), torch.zeros_like(vc)
+    lib.project_views(*args, ovf, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows4, mc4, vc4,
+                      segmap=maskbits_from_dense.last_labels_segmap, labels=lab)
+    assert torch.equal(rows4, rows) and torch.equal(mc4, mc) and torch.equal(vc4, vc)
     # and with the frustum-culling table of the point tiles (boxes may hold inf / 1e300 / denormals here)
     rows3, mc3, vc3 = torch.zeros_like(rows), torch.zeros_like(mc), torch.zeros_like(vc)
     lib.project_views(*args, bits, wb, i32([0]), i32([0]), i32([m]), i32([1]), rows3, mc3, vc3,

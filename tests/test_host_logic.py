@@ -53,7 +53,9 @@ def test_size_limits_are_rejected_on_the_host():
     assert lib.bff_resolve_overlaps(p, 257, 10, p, p, None, p, p, p, None) == -2 and b"256 rows" in lib.bff_last_error()
     assert lib.bff_resolve_overlaps_max_rows() == 256
     assert lib.bff_rle_to_maskbits(p, p, p, p, 1, 1 << 31, 32, p, None, None) == -2
-    assert lib.bff_project_views(p, 10, 1024, p, p, 1, p, p, 65536, 65536, 0.08, None, None, 32, None, None, None, p,
+    assert lib.bff_rle_to_labels(p, p, p, p, 1, 1 << 31, 32, p, p, None, None) == -2
+    assert lib.bff_rle_to_labels(p, p, p, p, 1, 100, 32, None, p, None, None) == -1
+    assert lib.bff_project_views(p, 10, 1024, p, p, 1, p, p, 65536, 65536, 0.08, None, None, None, 32, None, None, None, p,
                                  None, 0, 1, None, None, None, None, None) == -2 and b"2^31 pixels" in lib.bff_last_error()
 
 
