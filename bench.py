@@ -22,6 +22,7 @@ try:
     _NCPU = min(len(os.sched_getaffinity(0)), 32)
 except AttributeError:
     _NCPU = min(os.cpu_count() or 1, 32)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per scene in flight (see beyond_fixed_forms_amd/__init__.py)
 os.environ.setdefault("OPENBLAS_NUM_THREADS", str(_NCPU))
 os.environ.setdefault("OMP_NUM_THREADS", str(_NCPU))
 
@@ -40,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 from beyond_fixed_forms_amd import _lib, distributed as bdist  # noqa: E402
 from beyond_fixed_forms_amd.config import Config  # noqa: E402
+from beyond_fixed_forms_amd.pipeline import PIPELINE_DEPTH  # noqa: E402
 from beyond_fixed_forms_amd.projection import projection_back, projection_front  # noqa: E402
 from beyond_fixed_forms_amd.refinement import TextSimilarity, prepare_stage1, refine_class  # noqa: E402
 from beyond_fixed_forms_amd.scene import prepare_scene  # noqa: E402
@@ -284,6 +286,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish every scene before starting the next (default: the device work of the next "
                          "scene is issued on a second HIP stream while the host finishes the current one)")
+    ap.add_argument("--depth", type=int, default=PIPELINE_DEPTH, help="scenes in flight on the device (one HIP stream each)")
     ap.add_argument("--scenes", type=int, default=4, help="resident scenes rotated through the timed loop")
     ap.add_argument("--include-upload", action="store_true",
                     help="also report the host-inclusive rate: every step takes host arrays (reference formats, raw "
@@ -335,14 +338,15 @@ def main():
         dist.barrier()
 
     timers = KernelTimers()
-    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    depth = max(2, args.depth)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     host = {"front_issue_s": 0.0, "back_s": 0.0}     # host wall time per half (back includes its sync wait)
     results = {}
 
     def front(i, tm=None):
         t = time.perf_counter()
         k = i % n_scenes
-        with torch.cuda.stream(streams[i % 2]):
+        with torch.cuda.stream(streams[i % depth]):
             fr = projection_front(dss[k], cfg, timers=tm, stage1=stage1s[k])
         host["front_issue_s"] += time.perf_counter() - t
         return fr
@@ -356,7 +360,7 @@ def main():
 
     def _back(i, fr):
         k = i % n_scenes
-        with torch.cuda.stream(streams[i % 2]):
+        with torch.cuda.stream(streams[i % depth]):
             res = projection_back(fr, want_groups=False)
             fin = refine_class([(scenes[k].scene_id, stage1s[k], res)], cfg, QUERY, sim, dev, exchange_sims=exchange)
             rows = fin[scenes[k].scene_id].rows
@@ -375,12 +379,12 @@ def main():
             for i in range(k):
                 out = back(i, front(i, tm))
             return out
-        nxt = front(0, tm) if k else None
+        inflight, issued = [], 0
         for i in range(k):
-            cur = nxt
-            if i + 1 < k:
-                nxt = front(i + 1, tm)
-            out = back(i, cur)
+            while issued < k and issued - i < depth:       # scenes i .. i + depth - 1 are on the device
+                inflight.append(front(issued, tm))
+                issued += 1
+            out = back(i, inflight.pop(0))
         return out
 
     run_steps(args.warmup)
@@ -416,6 +420,20 @@ def main():
         run_steps(min(2 * n_scenes, args.steps), seq_timers)
         args.no_pipeline = was
         fence()
+
+    # device span of the one native call per scene (first kernel start -> last kernel end on an otherwise idle GPU,
+    # no host involvement in between): what the chain of ~50 launches costs end to end, per scene variant
+    spans = []
+    for k in range(n_scenes):
+        st = streams[k % depth]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(st)
+        fr = front(k)
+        e1.record(st)
+        back(k, fr)
+        torch.cuda.synchronize()
+        spans.append(round(e0.elapsed_time(e1), 4))
 
     upload_leg = None
     if args.include_upload and rank == 0:
@@ -455,7 +473,7 @@ def main():
                                    f"HBM (uploaded before the timed region); {n_scenes} different scenes rotate through the loop",
                        "scenes_per_step": world, "sharding": "one scene per GPU, RCCL gather of final masks",
                        "pipelining": "none" if args.no_pipeline else
-                       "2 HIP streams: the device work of scene i+1 overlaps the host half of scene i",
+                       f"{depth} HIP streams: the device work of the next {depth - 1} scene(s) overlaps the host half of scene i",
                        "scene_variants": [SCENE_VARIANTS[k % len(SCENE_VARIANTS)]["kind"] for k in range(n_scenes)]},
             "roofline": {"bound": "hbm", "kernel": "project_views_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -473,7 +491,7 @@ def main():
                                "l2_bytes_staged": l2_bytes, "achieved": l2_bytes / (mc_alone * 1e-3) / 1e9,
                                "peak": 34500.0, "unit": "GB/s (L2, MI355X_MICROARCH.md)",
                                "frac": l2_bytes / (mc_alone * 1e-3) / 1e9 / 34500.0, **mt},
-            "host_ms": host_ms,      # wall time of the host thread per step: issuing, the host half, and the part of it spent blocked on the GPU
+            "host_ms": host_ms, "scene_call_device_span_ms": spans,      # wall time of the host thread per step: issuing, the host half, and the part of it spent blocked on the GPU
             "kernels_ms": {k: round(vv[2], 4) for k, vv in ks.items()},   # the kernels' own durations (events on the dispatch)
             "result": {"per_scene (stage2_instances, final_masks)": [results.get(k) for k in range(n_scenes)]},
             "setup_s": round(t_setup, 1),

@@ -45,7 +45,14 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
     __shared__ uint64_t stage_all[kBlock / kWave][sizeof(WordT) * 8][kPPT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t word0 = (int64_t)blockIdx.x * kWordsPerBlock + (int64_t)wave * kPPT;   // the wave's first word
+    // Block -> XCD mapping is the plain round-robin of the dispatch order.  Both XCD-aware mappings were measured on
+    // config 2 and lost: an eighth of the (spatially sorted) cloud per XCD makes the work per XCD uneven -- frustum
+    // culling empties whole regions of a frame and dispatch is in order -- (0.34 -> 0.8 ms); one frame tile per XCD, so
+    // that a depth / mask line is fetched by one L2 only, ran 0.338 -> 0.345 ms alone and 0.44 -> 0.55 ms beside the other
+    // scenes' kernels: the lines re-fetched by other XCDs come out of the Infinity Cache, not HBM.
+    const int64_t bx = blockIdx.x;
+    const int f0 = blockIdx.y * frames_per_block;
+    const int64_t word0 = bx * kWordsPerBlock + (int64_t)wave * kPPT;   // the wave's first word
     const int64_t hw = (int64_t)H * W;
     uint64_t (*stage)[kPPT] = stage_all[wave];
 
@@ -64,7 +71,6 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
         vcount[j] = 0;
     }
 
-    const int f0 = blockIdx.y * frames_per_block;
     const int f1 = min(n_frames, f0 + frames_per_block);
     const double dW = (double)W, dH = (double)H;
     // Frustum culling of the wave's 256 points against the <= 8 frames of the tile, all at once: lane = 8 * frame

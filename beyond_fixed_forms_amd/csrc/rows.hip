@@ -2378,7 +2378,8 @@ extern "C" int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n
     BFF_LIMIT(slice_cap + 1 <= 65535, "bff_or_reduce_grouped: too many member slices");
     // through the chunk flags only when the rows are long (config 2: the dense pass runs at HBM speed and the flagged
     // form was measured slower; config 4: 4.8 GB of rows, ~1 % occupied)
-    const uint64_t *cm = (chunk_mask && nw >= 8192) ? chunk_mask : nullptr;
+    static const int64_t min_nw = [] { const char *e = getenv("BFF_OR_SPARSE_MIN_NW"); return e ? atoll(e) : 8192ll; }();
+    const uint64_t *cm = (chunk_mask && nw >= min_nw) ? chunk_mask : nullptr;
     const int mw = (int)ceil_div(ceil_div(nw, kCW), 64);
     if (conf_dtype == 1)
         or_reduce_grouped_kernel<__half><<<grid, 256, 0, st>>>(rows, nw, info, cap, offs, members, slices, slice_cap, out,

@@ -216,9 +216,11 @@ def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[floa
     mine = shard_scenes(ids, weights=weights)
     s_max = max(1, -(-len(scenes) // ws))                  # most scenes any rank owns
     with_viewed = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
-    # software pipeline over two HIP streams: the device work of scene k+1 is issued before the host finishes scene k
+    # software pipeline over PIPELINE_DEPTH HIP streams: the device work of the next scenes is issued before the host
+    # finishes scene k
+    from .pipeline import PIPELINE_DEPTH as depth
     on_gpu = torch.device(device).type == "cuda"
-    streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)] if on_gpu else None
+    streams = [torch.cuda.Stream(device=device) for _ in range(depth)] if on_gpu else None
 
     def front(k):
         sc = scenes[mine[k]]
@@ -226,24 +228,24 @@ def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[floa
         st1 = prepare_stage1(sc.stage1, device)
         if streams is None:
             return projection_front(ds, cfg, stage1=st1), st1
-        streams[k % 2].wait_stream(torch.cuda.current_stream())       # the uploads ran on the current stream
-        with torch.cuda.stream(streams[k % 2]):
+        streams[k % depth].wait_stream(torch.cuda.current_stream())   # the uploads ran on the current stream
+        with torch.cuda.stream(streams[k % depth]):
             return projection_front(ds, cfg, stage1=st1), st1
 
     def back(k, fr):
         if streams is None:
             return projection_back(fr)
-        with torch.cuda.stream(streams[k % 2]):
+        with torch.cuda.stream(streams[k % depth]):
             res = projection_back(fr)
-        torch.cuda.current_stream().wait_stream(streams[k % 2])       # results are used on the current stream
+        torch.cuda.current_stream().wait_stream(streams[k % depth])   # results are used on the current stream
         return res
 
-    trip = []
-    nxt = front(0) if mine else None
+    trip, inflight, issued = [], [], 0
     for k, i in enumerate(mine):
-        cur, st1 = nxt
-        if k + 1 < len(mine):
-            nxt = front(k + 1)
+        while issued < len(mine) and issued - k < depth:       # scenes k .. k + depth - 1 are on the device
+            inflight.append(front(issued))
+            issued += 1
+        cur, st1 = inflight.pop(0)
         trip.append((scenes[i].scene_id, st1, back(k, cur)))
     exchange = ClassExchange(device) if ws > 1 else None
     final = refine_class(trip, cfg, text_prompt, sim, device, exchange_sims=exchange) if trip or ws > 1 else {}

@@ -51,6 +51,12 @@ class WorkspaceStruct(ctypes.Structure):
                                                       ("hdr", c_void_p), ("hdr_host", c_void_p)]
 
 
+# Scenes in flight on the device, one HIP stream (and one SceneWorkspace) each.  A scene's device work is a chain of
+# ~50 launches of which three fill the chip; the rest of the chain only overlaps with OTHER scenes' kernels.  Measured
+# on config 2 (bench.py --depth): 2 -> 1.31 ms per scene, 3 -> 1.09, 4 -> 1.02, 6 -> 1.18 (the host thread, which
+# issues and collects every scene, and the chip are then both busy ~70 % of the time).
+PIPELINE_DEPTH = 4
+
 _checked = False
 
 
