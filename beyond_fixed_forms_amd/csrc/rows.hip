@@ -974,20 +974,29 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
 #pragma unroll
     for (int q = 1; q < 64; q <<= 1) { const int up = __shfl_up(incl, q); if (lane >= q) incl += up; }
     if (lane == 63) wbase[wv] = incl;
+    __shared__ unsigned long long s_live[2];                       // rows that still take part in a candidate pair
+    if (tid < 2) s_live[tid] = 0;
     __syncthreads();
     int pos = incl - mine_n;
     for (int q = 0; q < wv; ++q) pos += wbase[q];
     const int n_pairs = wbase[0] + wbase[1] + wbase[2] + wbase[3];
     if (tid == 0) g_block_info[0] = n_pairs | (s_cnt << 16);      // timeline diagnostics (mode 2) read this
+    // only the words of rows in a candidate pair are fetched below (the others stage as zeros)
     {
         unsigned cc = cand;
+        unsigned ra4 = 0, rb4 = 0;                                 // which of this thread's 4 + 4 rows appear
         while (cc) {
             const int q = __ffs(cc) - 1;
             cc &= cc - 1;
+            ra4 |= 1u << (q >> 2);
+            rb4 |= 1u << (q & 3);
             plist[pos++] = (uint16_t)(((ti * 4 + (q >> 2)) << 8) | (tj * 4 + (q & 3)));
         }
+        if (ra4) atomicOr(&s_live[0], (unsigned long long)ra4 << (ti * 4));
+        if (rb4) atomicOr(&s_live[1], (unsigned long long)rb4 << (tj * 4));
     }
     __syncthreads();
+    const uint64_t live_a = s_live[0], live_b = s_live[1];
     const int cnt = s_cnt;
     if (kDiag) {                                                   // diagnostics only
         if (tid == 0) { atomicAdd(diag + 0, 1); atomicAdd(diag + 1, cnt); atomicAdd(diag + 2, n_pairs); }
@@ -999,8 +1008,8 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int ra = rowA[lr + 8 * q], rb = rowB[lr + 8 * q];
-        pa[q] = ra >= 0 ? rows + (int64_t)ra * nw : nullptr;
-        pb[q] = rb >= 0 ? rows + (int64_t)rb * nw : nullptr;
+        pa[q] = (ra >= 0 && ((live_a >> (lr + 8 * q)) & 1)) ? rows + (int64_t)ra * nw : nullptr;
+        pb[q] = (rb >= 0 && ((live_b >> (lr + 8 * q)) & 1)) ? rows + (int64_t)rb * nw : nullptr;
     }
     // Staging is software pipelined: the words of stage g+1 are fetched into registers while stage g is
     // combined out of LDS, so a stage costs max(load latency, compute) instead of their sum.
