@@ -286,6 +286,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish every scene before starting the next (default: the device work of the next "
                          "scene is issued on a second HIP stream while the host finishes the current one)")
+    ap.add_argument("--host-profile", action="store_true", help="cProfile of the timed loop to stderr")
     ap.add_argument("--depth", type=int, default=PIPELINE_DEPTH, help="scenes in flight on the device (one HIP stream each)")
     ap.add_argument("--scenes", type=int, default=4, help="resident scenes rotated through the timed loop")
     ap.add_argument("--include-upload", action="store_true",
@@ -398,10 +399,19 @@ def main():
     fence()
     host.update(front_issue_s=0.0, back_s=0.0)
     _lib.sync_wait_s = 0.0
+    prof = None
+    if args.host_profile:                              # where the host thread's time goes (stderr; slows the loop)
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     run_steps(args.steps, timers)
     fence()
     elapsed = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(35)
     host_ms = {"front_issue": round(host["front_issue_s"] / args.steps * 1e3, 4),
                "back": round(host["back_s"] / args.steps * 1e3, 4),
                "of_which_waiting_for_gpu": round(_lib.sync_wait_s / args.steps * 1e3, 4)}

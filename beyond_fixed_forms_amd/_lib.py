@@ -33,7 +33,7 @@ SIGNATURES = {
     "bff_merge_adjacency": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "bff_permute_bits": [_P, _I, _L, _P, _L, _L, _P, _P],
     "bff_components_round": [_P, _I, _P, _P, _P, _P],
-    "bff_or_reduce_groups": [_P, _L, _P, _P, _I, _I, _P, _P, _I, _P, _P],
+    "bff_or_reduce_groups": [_P, _L, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P],
     "bff_resolve_overlaps": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P],
     "bff_group_conf_mean": [_P, _I, _P, _P, _I, _P, _P],
     "bff_apply_row_ops": [_P, _L, _P, _I, _P],
@@ -121,11 +121,23 @@ def _cached_stream():
     return getattr(_tls, "cache", None)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # the handle without building a Stream object
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def raw_stream():
+    """hipStream_t of torch's current stream on the current device as an int (torch.cuda.current_stream() costs ~8 us
+    of Python per call -- more than a kernel launch; a scene makes a dozen of them)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def _stream():
     c = _cached_stream()
     if c is not None:
         return c[0]
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p(raw_stream())
 
 
 class launch_stream:
@@ -370,7 +382,7 @@ def components(adj, max_rounds=10_000):
     raise RuntimeError("bff_components_round did not converge")
 
 
-def or_reduce_groups(rows, group_offs, members, max_group_size, conf=None):
+def or_reduce_groups(rows, group_offs, members, max_group_size, conf=None, chunk_mask=None):
     """out[g] = OR of the member rows.  conf given (float16/float32 per row): also returns the groups' sequential
     confidence means (group_conf_mean), computed by extra blocks of the same launch."""
     k = group_offs.shape[0] - 1
@@ -382,7 +394,7 @@ def or_reduce_groups(rows, group_offs, members, max_group_size, conf=None):
         mean = torch.empty(k, dtype=conf.dtype, device=conf.device)
     call("bff_or_reduce_groups", _ptr(rows, i64), rows.shape[1], _ptr(group_offs, i32), _ptr(members, i32), k,
          int(max_group_size), _ptr(out), _ptr(conf), 1 if (conf is not None and conf.dtype == torch.float16) else 0,
-         _ptr(mean))
+         _ptr(mean), _ptr(chunk_mask, i64))
     return out if conf is None else (out, mean)
 
 

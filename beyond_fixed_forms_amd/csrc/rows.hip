@@ -1314,8 +1314,9 @@ __global__ __launch_bounds__(256) void or_reduce_groups_kernel(const uint64_t *_
                                                                 const int32_t *__restrict__ offs,
                                                                 const int32_t *__restrict__ members, int n_groups,
                                                                 uint64_t *__restrict__ out, const T *__restrict__ conf,
-                                                                T *__restrict__ mean)
+                                                                T *__restrict__ mean, const uint64_t *__restrict__ cmask, int mw)
 {
+    __shared__ uint32_t s_occ[kOrSplit];           // cmask given: the members' chunk flags for this block's 256 words
     // blockIdx.z takes members [z*32, z*32+32) of group blockIdx.y; partial ORs meet in the zeroed output.
     // Blocks with blockIdx.y == 0 when conf != NULL (groups then start at y = 1) do not OR anything: their first wave
     // computes the sequential confidence means of groups blockIdx.x, blockIdx.x + gridDim.x, ... so that the
@@ -1329,10 +1330,23 @@ __global__ __launch_bounds__(256) void or_reduce_groups_kernel(const uint64_t *_
     }
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lo = offs[g] + blockIdx.z * kOrSplit, hi = min(offs[g + 1], lo + kOrSplit);
-    if (w >= nw || lo >= hi) return;
+    if (lo >= hi) return;                                          // block-uniform
     uint64_t v = 0;
+    if (cmask) {                                                   // long rows: see or_reduce_grouped_kernel
+        if (threadIdx.x < hi - lo) {
+            const uint64_t m64 = cmask[(int64_t)members[lo + threadIdx.x] * mw + (blockIdx.x >> 1)];
+            s_occ[threadIdx.x] = (uint32_t)(m64 >> (32 * (blockIdx.x & 1)));
+        }
+        __syncthreads();
+        if (w >= nw) return;
+        const int c = threadIdx.x >> 3;
+        for (int m = lo; m < hi; ++m)
+            if ((s_occ[m - lo] >> c) & 1) v |= rows[(int64_t)members[m] * nw + w];
+    } else {
+        if (w >= nw) return;
 #pragma unroll 8
-    for (int m = lo; m < hi; ++m) v |= rows[(int64_t)members[m] * nw + w];
+        for (int m = lo; m < hi; ++m) v |= rows[(int64_t)members[m] * nw + w];
+    }
     if (gridDim.z == 1) out[(int64_t)g * nw + w] = v;
     else if (v) atomicOr((unsigned long long *)(out + (int64_t)g * nw + w), (unsigned long long)v);
 }
@@ -2155,10 +2169,18 @@ extern "C" int bff_permute_bits(const uint64_t *rows_in, int32_t n_rows, int64_t
     return launched("bff_permute_bits");
 }
 
+// Rows at least this long are OR-ed through their chunk flags (BFF_OR_SPARSE_MIN_NW): config 4 reads 4.8 GB of rows
+// that are ~1 % occupied; at config 2 the dense pass (234 MB) and the flagged one measured the same end to end.
+static int64_t or_sparse_min_words()
+{
+    static const int64_t v = [] { const char *e = getenv("BFF_OR_SPARSE_MIN_NW"); return e ? atoll(e) : 8192ll; }();
+    return v;
+}
+
 extern "C" int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int32_t *group_offs,
                                     const int32_t *members, int32_t n_groups, int32_t max_group_size,
                                     uint64_t *out, const void *conf, int32_t conf_dtype, void *conf_mean,
-                                    void *stream)
+                                    const uint64_t *chunk_mask, void *stream)
 {
     BFF_REQUIRE(n_groups >= 0 && nw >= 0, "bff_or_reduce_groups: bad sizes");
     if (n_groups == 0) return BFF_OK;
@@ -2173,12 +2195,14 @@ extern "C" int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int3
         if (e != hipSuccess) return fail((int)e, "bff_or_reduce_groups: memset: %s", hipGetErrorString(e));
     }
     dim3 grid((unsigned)ceil_div(nw > 0 ? nw : 1, 256), (unsigned)(n_groups + (conf ? 1 : 0)), (unsigned)nz);
+    const uint64_t *cm = (chunk_mask && nw >= or_sparse_min_words()) ? chunk_mask : nullptr;
+    const int mw = (int)ceil_div(ceil_div(nw, kCW), 64);
     if (conf_dtype == 1)
         or_reduce_groups_kernel<__half><<<grid, 256, 0, as_stream(stream)>>>(rows, nw, group_offs, members, n_groups, out,
-                                                                            (const __half *)conf, (__half *)conf_mean);
+                                                                            (const __half *)conf, (__half *)conf_mean, cm, mw);
     else
         or_reduce_groups_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(rows, nw, group_offs, members, n_groups, out,
-                                                                           (const float *)conf, (float *)conf_mean);
+                                                                           (const float *)conf, (float *)conf_mean, cm, mw);
     return launched("bff_or_reduce_groups");
 }
 
@@ -2387,8 +2411,7 @@ extern "C" int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n
     BFF_LIMIT(slice_cap + 1 <= 65535, "bff_or_reduce_grouped: too many member slices");
     // through the chunk flags only when the rows are long (config 2: the dense pass runs at HBM speed and the flagged
     // form was measured slower; config 4: 4.8 GB of rows, ~1 % occupied)
-    static const int64_t min_nw = [] { const char *e = getenv("BFF_OR_SPARSE_MIN_NW"); return e ? atoll(e) : 8192ll; }();
-    const uint64_t *cm = (chunk_mask && nw >= min_nw) ? chunk_mask : nullptr;
+    const uint64_t *cm = (chunk_mask && nw >= or_sparse_min_words()) ? chunk_mask : nullptr;
     const int mw = (int)ceil_div(ceil_div(nw, kCW), 64);
     if (conf_dtype == 1)
         or_reduce_grouped_kernel<__half><<<grid, 256, 0, st>>>(rows, nw, info, cap, offs, members, slices, slice_cap, out,

@@ -133,11 +133,13 @@ class SceneWorkspace:
 
     @classmethod
     def for_current_stream(cls, device):
-        st = torch.cuda.current_stream(device)
-        key = (st.device.index, st.cuda_stream)
+        dev = torch.device(device)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), _lib.raw_stream())
         ws = cls._per_stream.get(key)
         if ws is None:
+            st = torch.cuda.current_stream(device)
             ws = cls._per_stream[key] = cls(st.device)
+            ws.stream = st                    # the stream this workspace belongs to (the key above is its raw handle)
         return ws
 
     def _need(self, name, numel, dtype, zero=False):
@@ -235,7 +237,7 @@ def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
     pr = params_struct(cfg, depth_thresh, filter_sort=use_sort)
     ws.in_flight = True
     _lib.call("bff_scene_project", ctypes.byref(sc), ctypes.byref(pr), ctypes.byref(ws.struct))
-    return dict(ws=ws, both=both, s1_rows=s1_rows, params=pr, stream=torch.cuda.current_stream(dev),
+    return dict(ws=ws, both=both, s1_rows=s1_rows, params=pr, stream=ws.stream,
                 args=(ds, cfg, depth_thresh, stage1, n_frames))
 
 

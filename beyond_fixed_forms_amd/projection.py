@@ -347,9 +347,16 @@ def _fast_back(fr: _Front, stage1, want_groups) -> Stage2Result:
                keep=torch.from_numpy(keep_rows))
     agg_u = both[:GROUP_CAP]
     if sel.size:
-        out_rows = _lib.gather_rows(agg_u, _lib.upload(sel, torch.int32, dev))
-        conf_host = torch.from_numpy(conf_np[sel].copy())
-        out_conf = _lib.upload(conf_np[sel], ds.conf.dtype, dev)
+        # one upload for the row selection and the kept confidences (raw bytes behind the int32 indices)
+        conf_sel = np.ascontiguousarray(conf_np[sel])
+        n_sel, cw = sel.size, (conf_sel.nbytes + 3) // 4
+        packed = np.zeros(n_sel + cw, dtype=np.int32)
+        packed[:n_sel] = sel
+        packed[n_sel:].view(np.uint8)[:conf_sel.nbytes] = conf_sel.view(np.uint8)
+        packed_d = _lib.upload(packed, torch.int32, dev)
+        out_rows = _lib.gather_rows(agg_u, packed_d[:n_sel])
+        conf_host = torch.from_numpy(conf_sel.copy())
+        out_conf = packed_d[n_sel:].view(ds.conf.dtype)[:n_sel]
     else:
         out_rows = agg_u[:0]
         conf_host = torch.from_numpy(conf_np[:0].copy())
@@ -450,7 +457,7 @@ def _projection_back(fr: _Front, timers, phases, stage1=None) -> Stage2Result:
     n_offs, n_mem = offs.shape[0], members.shape[0]
     packed = _lib.upload(np.concatenate([offs, members, sizes.astype(np.int32, copy=False)]), torch.int32, dev)
     offs_d, members_d, sizes_d = packed[:n_offs], packed[n_offs:n_offs + n_mem], packed[n_offs + n_mem:]
-    agg, conf = _lib.or_reduce_groups(rows, offs_d, members_d, int(sizes.max()), ds.conf)
+    agg, conf = _lib.or_reduce_groups(rows, offs_d, members_d, int(sizes.max()), ds.conf, chunk_mask=fr.cmask)
     first_member = members[offs[:-1]]
     agg_labels = [ds.labels[i] for i in first_member]
     if not debug_out:

@@ -238,9 +238,10 @@ def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: Text
     other = [i for i, lab in enumerate(s1_labels) if lab == query_us and i not in taken]    # R:293
     labels = [s1_labels[i] for i in best_l]                                         # R:297
     sims = sim.similarities(text_prompt, labels)                                    # R:299-302
+    picks = i32(best_l + other)                                                      # one upload for both selections
     return _SceneState(scene_id, n, iou[np.arange(len(best_l)), best], sims,
-                       _lib.gather_rows(s1, i32(best_l)), s2, conf2,
-                       _lib.gather_rows(s1, i32(other)) if other else s1[:0])
+                       _lib.gather_rows(s1, picks[:len(best_l)]), s2, conf2,
+                       _lib.gather_rows(s1, picks[len(best_l):]) if other else s1[:0])
 
 
 @dataclasses.dataclass

@@ -260,10 +260,11 @@ int bff_components_round(const uint64_t *adj, int32_t n_nodes, const int32_t *la
 /* a13: out[g] = OR of rows[members[group_offs[g] .. group_offs[g+1])]      (merge_masks P:219-224;
  * also the `.any(dim=0)` merge of R:269).  max_group_size >= the largest group (host knows the groups);
  * it only sizes the launch.  conf / conf_mean (optional, both or neither; dtype as bff_group_conf_mean): the
- * same launch also computes bff_group_conf_mean on extra blocks, so the long sequential sums run beside the OR. */
+ * same launch also computes bff_group_conf_mean on extra blocks, so the long sequential sums run beside the OR.
+ * chunk_mask (optional, the rows' chunk flags): long rows are read through it. */
 int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int32_t *group_offs, const int32_t *members,
                          int32_t n_groups, int32_t max_group_size, uint64_t *out, const void *conf,
-                         int32_t conf_dtype, void *conf_mean, void *stream);
+                         int32_t conf_dtype, void *conf_mean, const uint64_t *chunk_mask, void *stream);
 
 /* a13: mean[g] = (((c[m0] + c[m1]) + c[m2]) ...) / len, every step rounded to the confidence dtype
  * (P:225: python `sum(conf) / len(conf)` over 0-dim tensors).  dtype: 0 = float32, 1 = float16. */

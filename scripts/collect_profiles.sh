@@ -23,7 +23,7 @@ summarize() { python3 scripts/prof_summarize.py $RAW "$OUT" ${1:-bff} > /dev/nul
 for part in $PARTS; do case $part in
 stats)
     run stats rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -- $B --steps 12 --warmup 4
-    tail -1 $RAW.stats.log > "$OUT/bench_c2_under_rocprof.json"
+    grep '^{"metric"' $RAW.stats.log | tail -1 > "$OUT/bench_c2_under_rocprof.json"
     python3 scripts/pipeline_occupancy.py $RAW/stats 8 > "$OUT/pipeline_occupancy.txt"
     summarize ;;
 seq)

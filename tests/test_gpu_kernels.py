@@ -391,6 +391,37 @@ def test_or_reduce_and_conf_mean(lib, dtype):
     assert torch.equal(out2, out) and torch.equal(got2.cpu(), exp)
 
 
+def test_or_reduce_long_rows_through_chunk_flags(lib):
+    """Rows of >= 8192 words (config 4 is 15 625) are OR-ed through their chunk flags: same result as the dense pass,
+    members' words outside their flagged chunks are never read (poisoned here)."""
+    rng = np.random.default_rng(11)
+    r, nw = 90, 8192 + 77
+    n = nw * 64 - 13
+    rows = torch.zeros((r, nw), dtype=torch.int64, device=DEV)
+    dense = np.zeros((r, nw), np.uint64)
+    for i in range(r):                                   # a few occupied 8-word chunks per row, some shared
+        for c in rng.choice(nw // 8, size=int(rng.integers(0, 12)), replace=False):
+            dense[i, 8 * c:8 * c + 8] = rng.integers(0, 2 ** 63, 8, dtype=np.uint64) * (rng.random(8) < 0.6)
+    dense[3, -5:] = np.uint64(7)                          # the ragged last chunk
+    dense[:, -1] &= np.uint64((1 << (64 - 13)) - 1)
+    rows.copy_(torch.from_numpy(dense.view(np.int64)))
+    stats = lib.row_stats(rows)
+    cm = stats[2]
+    # poison every unflagged chunk: the flagged pass must not see it
+    flags = np.unpackbits(cm.cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[:, :(nw + 7) // 8].astype(bool)
+    poisoned = dense.copy()
+    per_word = np.repeat(flags, 8, axis=1)[:, :nw]
+    poisoned[~per_word] = np.uint64(0xDEADBEEF)
+    rows_p = torch.from_numpy(poisoned.view(np.int64)).to(DEV)
+    groups = [[0, 1, 2], [3], list(range(4, 80)), [89, 85]]
+    offs = torch.tensor(np.cumsum([0] + [len(g) for g in groups]), dtype=torch.int32, device=DEV)
+    mem = torch.tensor([i for g in groups for i in g], dtype=torch.int32, device=DEV)
+    exp = np.stack([np.bitwise_or.reduce(dense[g], axis=0) for g in groups])
+    got = lib.or_reduce_groups(rows_p, offs, mem, max(len(g) for g in groups), chunk_mask=cm)
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), exp)
+    assert np.array_equal(lib.or_reduce_groups(rows, offs, mem, max(len(g) for g in groups)).cpu().numpy().view(np.uint64), exp)
+
+
 def test_row_ops_and_rows(lib):
     rng = np.random.default_rng(8)
     r, n = 6, 500
