@@ -130,6 +130,7 @@ class SceneWorkspace:
         self.hdr_host = None
         self.in_flight = False
         self.rows_dirty = False
+        self.both_primed = 0
 
     @classmethod
     def for_current_stream(cls, device):
@@ -217,6 +218,10 @@ class SceneWorkspace:
 
 def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
     """Enqueue the whole device side of one scene on the current stream.  Returns a handle for `collect`."""
+    import time as _time
+    _t0 = _time.perf_counter()
+    _marks = []
+    _mark = lambda name: _marks.append((name, round((_time.perf_counter() - _t0) * 1e3, 3)))
     dev = ds.xyz.device
     key = (id(stage1), n_frames)
     cache = ds.__dict__.setdefault("_scene_structs", {})
@@ -225,10 +230,20 @@ def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
         ent = cache[key] = (scene_struct(ds, stage1, n_frames), stage1)      # keeps stage1's tensors alive too
     sc = ent[0]
     s1_rows = int(sc.s1_rows)
+    _mark("struct")
     ws = SceneWorkspace.for_current_stream(dev).fit(ds, s1_rows)
+    _mark("fit")
     if ws.in_flight or ws.rows_dirty:             # a call whose results were never collected: the arena may be dirty
         ws.t["rows"].zero_()
         ws.rows_dirty = False
+    n_both = (GROUP_CAP + s1_rows) * ds.nw
+    if ws.both_primed < n_both:
+        # `both` outlives the workspace's reuse (results are views of it), so it comes from torch's allocator, whose
+        # pools are per stream: the first few scenes of a stream would each pay a hipMalloc (~6 ms) until the pool
+        # holds the 3-4 blocks that are alive at a time.  Take and return them once, when the workspace is sized.
+        prime = [torch.empty(n_both, dtype=torch.int64, device=dev) for _ in range(4)]
+        del prime
+        ws.both_primed = n_both
     both = torch.empty((GROUP_CAP + s1_rows, ds.nw), dtype=torch.int64, device=dev)     # outlives the workspace's reuse
     ws.struct.both = c_void_p(both.data_ptr())
     # the threshold of the point filter: radix sort of all values (default) or the distinct-value set (BFF_FILTER_SET=1;
@@ -236,7 +251,12 @@ def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
     use_sort = os.environ.get("BFF_FILTER_SET") != "1" or bool(ds.__dict__.get("_filter_sort", False))
     pr = params_struct(cfg, depth_thresh, filter_sort=use_sort)
     ws.in_flight = True
+    _mark("both")
     _lib.call("bff_scene_project", ctypes.byref(sc), ctypes.byref(pr), ctypes.byref(ws.struct))
+    _mark("call")
+    if _marks[-1][1] > 2.0 and os.environ.get("BFF_TRACE_ISSUE"):
+        import sys
+        print("slow issue:", _marks, file=sys.stderr)
     return dict(ws=ws, both=both, s1_rows=s1_rows, params=pr, stream=ws.stream,
                 args=(ds, cfg, depth_thresh, stage1, n_frames))
 

@@ -9,8 +9,28 @@ import torch
 
 
 class KernelTimers:
-    def __init__(self):
+    def __init__(self, reserve: int = 0):
+        """reserve: native events created up front (hipEventCreate costs ~0.2 ms apiece the first few hundred times;
+        a timed loop must not pay for it: bench.py reserves 4 per step before the clock starts)."""
         self._events = defaultdict(list)
+        self._pool = []
+        if reserve:
+            from . import _lib
+            lib = _lib.load()
+            for _ in range(reserve):
+                e = lib.bff_event_create()
+                if not e:
+                    raise RuntimeError("bff_event_create failed")
+                self._pool.append(e)
+
+    def _native_event(self):
+        if self._pool:
+            return self._pool.pop()
+        from . import _lib
+        e = _lib.load().bff_event_create()
+        if not e:
+            raise RuntimeError("bff_event_create failed")
+        return e
 
     @contextlib.contextmanager
     def span(self, name):
@@ -27,9 +47,7 @@ class KernelTimers:
         import ctypes
         from . import _lib
         lib = _lib.load()
-        a, b = lib.bff_event_create(), lib.bff_event_create()
-        if not a or not b:
-            raise RuntimeError("bff_event_create failed")
+        a, b = self._native_event(), self._native_event()
         lib.bff_profile_next_sweep(a, b)
         yield
         self._events[name].append((ctypes.c_void_p(a), ctypes.c_void_p(b)))
@@ -40,9 +58,7 @@ class KernelTimers:
         import ctypes
         from . import _lib
         lib = _lib.load()
-        a, b = lib.bff_event_create(), lib.bff_event_create()
-        if not a or not b:
-            raise RuntimeError("bff_event_create failed")
+        a, b = self._native_event(), self._native_event()
         lib.bff_profile_next_merge(a, b)
         yield
         self._events[name].append((ctypes.c_void_p(a), ctypes.c_void_p(b)))
@@ -74,6 +90,10 @@ class KernelTimers:
                     _lib.load().bff_event_destroy(a)
                     _lib.load().bff_event_destroy(b)
         self._events.clear()
+        for e in self._pool:
+            from . import _lib
+            _lib.load().bff_event_destroy(e)
+        self._pool = []
 
 
 @contextlib.contextmanager
