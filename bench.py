@@ -503,6 +503,10 @@ def main():
                          "traffic_detail": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": pv[2], "launches": pv[0],
                          "survey_row_write_bytes_not_credited": zbytes,
+                         "note": "avg_launch_ms is the kernel's duration INSIDE the timed loop, where it shares the chip with the "
+                                 "kernels of the other scenes in flight (HIP events on the dispatch); `alone_on_chip` is the same "
+                                 "kernel in a strictly sequential loop right after it and is what a rocprofv3 kernel trace "
+                                 "shows, because the profiler serialises the streams (profiles/README.md)",
                          "compulsory": comp,
                          "alone_on_chip": {"avg_launch_ms": sq["project_views"][2],
                                            "achieved": abytes / (sq["project_views"][2] * 1e-3) / 1e9,
