@@ -24,21 +24,40 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_kernel(const _Float16 *__
     if (j0 >= nb) return;                                     // wave-uniform
     const int r = lane & 15, kq = lane >> 4;                  // fragment: row/col r, k = 8*kq .. 8*kq+7
     const bool ra = i0 + r < na, rb = j0 + r < nb;
-    const _Float16 *pa = a + (int64_t)(ra ? i0 + r : 0) * dim + 8 * kq;
-    const _Float16 *pb = b + (int64_t)(rb ? j0 + r : 0) * dim + 8 * kq;
+    const _Float16 *a_row = a + (int64_t)(ra ? i0 + r : 0) * dim;
+    const _Float16 *b_row = b + (int64_t)(rb ? j0 + r : 0) * dim;
     float4v acc = {0.f, 0.f, 0.f, 0.f};
     float sa = 0.f, sb = 0.f;
     const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k0 = 0; k0 < dim; k0 += 32) {
-        const half8 fa = ra ? *reinterpret_cast<const half8 *>(pa + k0) : zero;
-        const half8 fb = rb ? *reinterpret_cast<const half8 *>(pb + k0) : zero;
+    // A trip covers 128 k: lane (r, kq) loads the 64 contiguous bytes k0 + 32 kq .. + 31 of its row (the four lanes of
+    // a row read two whole 128-B lines) and feeds 8 of them to each of 4 MFMAs.  That permutes k inside the trip --
+    // identically for A and B, so every product still meets its partner; only the order of the float32 additions
+    // differs.  (With the natural fragment layout a lane reads 16 B of every 64: each line is fetched twice, by two
+    // different k-steps, and the L1 is far too small to hold it in between -- the kernel ran at the L2's transaction
+    // rate.)  Two trips' loads are issued before their MFMAs.
+    constexpr int kT2 = 2;
+    for (int k0 = 0; k0 < dim; k0 += 128 * kT2) {
+        half8 fa[kT2][4], fb[kT2][4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = (float)fa[e], y = (float)fb[e];
-            sa = fmaf(x, x, sa);
-            sb = fmaf(y, y, sb);
-        }
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc, 0, 0, 0);
+        for (int t = 0; t < kT2; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 128 * t + 32 * kq + 8 * u;      // dim is a multiple of 32: a fragment is in or out
+                fa[t][u] = (ra && k < dim) ? *reinterpret_cast<const half8 *>(a_row + k) : zero;
+                fb[t][u] = (rb && k < dim) ? *reinterpret_cast<const half8 *>(b_row + k) : zero;
+            }
+#pragma unroll
+        for (int t = 0; t < kT2; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = (float)fa[t][u][e], y = (float)fb[t][u][e];
+                    sa = fmaf(x, x, sa);
+                    sb = fmaf(y, y, sb);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[t][u], fb[t][u], acc, 0, 0, 0);
+            }
     }
     // the four k-quarters of a row live in lanes r, r+16, r+32, r+48
     sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);
