@@ -1060,7 +1060,10 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
         flushed = n_edges;
     };
     constexpr int kStep = kKW / kCW;                               // chunks per stage
-    constexpr int kSparse = 3;                                     // pair-list path: at most 3 pairs per thread
+    // pair-list path: at most 6 pairs per thread (1536 of the 4096).  3 was the first choice; interleaved A/B at config 2:
+    // tile pass alone 0.384 -> 0.328 ms going from 3 to 6 (a pair-list stage costs ~4 us, a 4x4-block stage ~11); 8 would
+    // cost the third block per CU (170 VGPRs)
+    constexpr int kSparse = 6;
     // settle pairs every `check_every` stages: 2 at first; a settle phase that closes no pair doubles the interval
     // (tiles between two groups of one object never settle early: their phases would cost as much as the counting)
     int check_every = 2, next_check = 2;
