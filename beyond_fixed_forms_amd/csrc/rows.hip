@@ -1060,10 +1060,12 @@ __device__ __forceinline__ void merge_tile_pair(int t, uint64_t pass_a, uint64_t
         flushed = n_edges;
     };
     constexpr int kStep = kKW / kCW;                               // chunks per stage
-    // pair-list path: at most 6 pairs per thread (1536 of the 4096).  3 was the first choice; interleaved A/B at config 2:
-    // tile pass alone 0.384 -> 0.328 ms going from 3 to 6 (a pair-list stage costs ~4 us, a 4x4-block stage ~11); 8 would
-    // cost the third block per CU (170 VGPRs)
-    constexpr int kSparse = 6;
+    // pair-list path: at most 7 pairs per thread (1792 of the 4096).  3 was the first choice; interleaved A/B at config 2
+    // (library variants side by side, BFF_HIP_LIB): tile pass alone 0.34 ms with 3, 0.30 with 6, 0.283-0.291 with 7, 0.31-0.33
+    // with 10 (a pair-list stage costs ~4 us at 3 pairs per thread and grows with them, a 4x4-block stage ~11 us);
+    // 8 and more need __launch_bounds__(256, 3) to stay at three blocks per CU.  Staging tile B permuted so that the 4x4
+    // pass reads 16 consecutive words instead of 16 words 32 B apart was measured too: 0.34 ms (slower).
+    constexpr int kSparse = 7;
     // settle pairs every `check_every` stages: 2 at first; a settle phase that closes no pair doubles the interval
     // (tiles between two groups of one object never settle early: their phases would cost as much as the counting)
     int check_every = 2, next_check = 2;
