@@ -296,7 +296,6 @@ def main():
                     help="finish every scene before starting the next (default: the device work of the next "
                          "scene is issued on a second HIP stream while the host finishes the current one)")
     ap.add_argument("--host-profile", action="store_true", help="cProfile of the timed loop to stderr")
-    ap.add_argument("--issue-thread", action="store_true", help="issue the scene calls from a helper thread")
     ap.add_argument("--depth", type=int, default=PIPELINE_DEPTH, help="scenes in flight on the device (one HIP stream each)")
     ap.add_argument("--scenes", type=int, default=4, help="resident scenes rotated through the timed loop")
     ap.add_argument("--include-upload", action="store_true",
@@ -355,15 +354,6 @@ def main():
     results = {}
 
     trace_front = [] if os.environ.get("BFF_BENCH_TRACE_FRONT") else None
-    # --issue-thread: the native scene call (~0.2 ms, GIL released inside ctypes) is made by a helper thread while the
-    # main thread does the host half of an earlier scene; a workspace is only reused after its scene was collected,
-    # and that happens-before the submit of the next scene on the same stream
-    issuer = None
-    if args.issue_thread and not args.no_pipeline:
-        from concurrent.futures import ThreadPoolExecutor
-        issuer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="bff-issue")
-        issuer.submit(torch.cuda.set_device, dev).result()
-
     def front(i, tm=None):
         t = time.perf_counter()
         k = i % n_scenes
@@ -405,10 +395,9 @@ def main():
         inflight, issued = [], 0
         for i in range(k):
             while issued < k and issued - i < depth:       # scenes i .. i + depth - 1 are on the device
-                inflight.append(issuer.submit(front, issued, tm) if issuer is not None else front(issued, tm))
+                inflight.append(front(issued, tm))
                 issued += 1
-            cur = inflight.pop(0)
-            out = back(i, cur.result() if issuer is not None else cur)
+            out = back(i, inflight.pop(0))
         return out
 
     # Priming (setup, not part of the W warm-up steps the contract asks for): the first ~14 scene calls of a process
@@ -445,9 +434,6 @@ def main():
                "back": round(host["back_s"] / args.steps * 1e3, 4),
                "of_which_waiting_for_gpu": round(_lib.sync_wait_s / args.steps * 1e3, 4)}
     host_ms["host_work"] = round(host_ms["front_issue"] + host_ms["back"] - host_ms["of_which_waiting_for_gpu"], 4)
-    if issuer is not None:          # front_issue ran on the helper thread, beside the main thread's back half
-        host_ms["issue_thread"] = True
-        host_ms["main_thread_work"] = round(host_ms["back"] - host_ms["of_which_waiting_for_gpu"], 4)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
