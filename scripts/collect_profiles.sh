@@ -5,6 +5,7 @@
 #   stats  kernel stats + trace summary of the bench command, pipelined occupancy
 #   seq    strictly sequential step timeline
 #   pmc2   separate FETCH_SIZE / WRITE_SIZE counter passes, config 2        pmc4   the same for config 4
+#   sq     SQ counters (wait / active / LDS conflicts) of the three chip-filling kernels, two passes
 #   cal    FETCH_SIZE on access patterns with a known number of distinct lines (scripts/diag_membw.py)
 #   bench  the bench lines of the same build
 # Counter passes collect only this library's kernels (--kernel-include-regex): the synthetic scene generator issues
@@ -39,6 +40,14 @@ pmc4)
     run pmc_fetch_c4 rocprofv3 --pmc FETCH_SIZE --kernel-trace $INC --output-format csv -d $RAW/pmc_fetch_c4 -- $B --shape c4 --scenes 2 --steps 4 --warmup 2 --no-pipeline
     summarize
     run pmc_write_c4 rocprofv3 --pmc WRITE_SIZE --kernel-trace $INC --output-format csv -d $RAW/pmc_write_c4 -- $B --shape c4 --scenes 2 --steps 4 --warmup 2 --no-pipeline
+    summarize ;;
+sq)
+    # where the waves' cycles go in the three chip-filling kernels (quad-cycles, MI355X_MICROARCH.md): parked on
+    # s_waitcnt / barriers, issue stalls, active; LDS array cycles and the extra cycles of bank conflicts
+    K3="--kernel-include-regex merge_components_kernel|project_views_kernel|rle_to_maskbits_kernel"
+    run sq1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace $K3 --output-format csv -d $RAW/sq1 -- $B --steps 8 --warmup 4 --no-pipeline
+    summarize
+    run sq2 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAVES SQ_INSTS_SALU --kernel-trace $K3 --output-format csv -d $RAW/sq2 -- $B --steps 8 --warmup 4 --no-pipeline
     summarize ;;
 cal)
     run cal_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace $INC --output-format csv -d $RAW/cal_fetch -- python3 scripts/diag_membw.py
