@@ -212,11 +212,12 @@ def bench_cosine(args):
         "config": {"workload": "c5: 9000 x 768 f16 features against a 200 x 768 f16 bank, f32 accumulate + normalise"},
         "roofline": {"bound": "mfma", "kernel": "cosine_gemm_f16_kernel", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None,
-                     "note": "2.8 GFLOP per launch (SURVEY section 8d).  One wave per 16x16 tile reads its 16 rows of A and of "
-                             "the bank: 7319 waves x 48 KB = 351 MB per launch = 6.7 TB/s -- A (13.8 MB) does not fit one XCD's "
-                             "L2 and is fetched again for each of the 13 column tiles; the kernel is bound by that traffic, "
-                             "not by MFMA issue (timed with the launch arguments hoisted: a Python-level launch costs as much "
-                             "as the kernel)"},
+                     "note": "2.8 GFLOP per launch (SURVEY section 8d).  One block per 16 rows of A, k split over its 4 waves, every "
+                             "wave against all 13 column tiles: A (13.8 MB) is read once, the bank (0.3 MB) by every block out of "
+                             "L2.  563 blocks x 4 waves is half a wave per SIMD slot: the kernel is bound by the latency of its 6 "
+                             "rounds of 14 fragment loads per wave, not by MFMA issue (SQ counters: 43 % parked, 34 % issue stalls, "
+                             "23 % active).  The one-wave-per-tile kernel it replaces for wide banks re-read A for each column "
+                             "tile: 52-60 us"},
         "max_abs_err_vs_f64": err}))
 
 

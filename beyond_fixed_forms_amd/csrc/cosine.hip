@@ -73,6 +73,93 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_kernel(const _Float16 *__
 }
 
 
+// Row-tile form for wide banks (nb > 64): one block per 16 rows of A, the k range split over its 4 waves, every wave
+// against ALL column tiles (13 at a time: 52 accumulator registers).  A is then read exactly once (13.8 MB at 9000 x 768
+// instead of once per column tile -- it does not fit one XCD's L2, so those re-reads came from beyond it), the bank
+// (0.3 MB) is read by every block out of L2, and the four partial sums of a tile meet in LDS.  The products are the
+// same, only the order of the float32 additions differs from the one-wave-per-tile kernel (k quarters summed last).
+// acc + the sum of the squares of 8 halves: four v_dot2_f32_f16 (exact products, float32 accumulation)
+__device__ __forceinline__ float sumsq8(half8 v, float acc)
+{
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const half2v p = {v[e], v[e + 1]};
+        acc = __builtin_amdgcn_fdot2(p, p, acc, false);
+    }
+    return acc;
+}
+
+constexpr int kCT = 13;                                        // column tiles per pass: 208 columns (ScanNet200: 198 + 2)
+__global__ __launch_bounds__(256) void cosine_gemm_f16_rows_kernel(const _Float16 *__restrict__ a, int na,
+                                                                    const _Float16 *__restrict__ b, int nb, int dim,
+                                                                    float *__restrict__ out, int norm_b)
+{
+    __shared__ float4v red[3][kCT][64];                        // partial accumulators of waves 1..3: [wave - 1][tile][lane]
+                                                               // (39 KB: three blocks per CU, all 563 of config 5 resident)
+    __shared__ float red_sa[4][16], red_sb[4][kCT][16];        // partial squared norms: rows of A, columns per tile
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 16;
+    const int r = lane & 15, kq = lane >> 4;                   // fragment: row/col r, k = 8*kq .. 8*kq+7
+    const int steps = dim / 32, per = (steps + 3) / 4;         // k-steps of this wave: [wave * per, min(steps, ...))
+    const int s_lo = wave * per, s_hi = min(steps, s_lo + per);
+    const bool ra = i0 + r < na;
+    const _Float16 *a_row = a + (int64_t)(ra ? i0 + r : 0) * dim + 8 * kq;
+    const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int n_ct = (nb + 15) / 16;
+    for (int c0 = 0; c0 < n_ct; c0 += kCT) {                   // block-uniform
+        float4v acc[kCT];
+        float sbn[kCT];
+#pragma unroll
+        for (int t = 0; t < kCT; ++t) { acc[t] = float4v{0.f, 0.f, 0.f, 0.f}; sbn[t] = 0.f; }
+        float sa = 0.f;
+        for (int st = s_lo; st < s_hi; ++st) {
+            const int k0 = st * 32;
+            const half8 fa = ra ? *reinterpret_cast<const half8 *>(a_row + k0) : zero;
+            half8 fb[kCT];
+#pragma unroll
+            for (int t = 0; t < kCT; ++t) {                    // all of the step's bank fragments in flight together
+                const int j = (c0 + t) * 16 + r;
+                fb[t] = j < nb ? *reinterpret_cast<const half8 *>(b + (int64_t)j * dim + 8 * kq + k0) : zero;
+            }
+            sa = sumsq8(fa, sa);
+#pragma unroll
+            for (int t = 0; t < kCT; ++t) {
+                if (norm_b) sbn[t] = sumsq8(fb[t], sbn[t]);    // every block recomputes the bank's norms: keep it to 4 ops
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[t], acc[t], 0, 0, 0);
+            }
+        }
+        // the four k-quarters of a row / column live in lanes r, r+16, r+32, r+48
+        sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);
+#pragma unroll
+        for (int t = 0; t < kCT; ++t) {
+            sbn[t] += __shfl_xor(sbn[t], 16); sbn[t] += __shfl_xor(sbn[t], 32);
+            if (wave) red[wave - 1][t][lane] = acc[t];
+            if (lane < 16) red_sb[wave][t][lane] = sbn[t];
+        }
+        if (lane < 16) red_sa[wave][lane] = sa;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kCT; ++t) {                        // wave 0 adds the other waves' k-quarters to its own and stores
+            if (wave != 0 || c0 + t >= n_ct) continue;
+            float4v sum = acc[t];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) { const float4v p = red[w][t][lane]; sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3]; }
+            const float sbj = red_sb[0][t][r] + red_sb[1][t][r] + red_sb[2][t][r] + red_sb[3][t][r];
+            const float nbj = norm_b ? sqrtf(sbj) : 1.0f;      // column (c0 + t) * 16 + (lane & 15)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = kq * 4 + q;                    // C/D map: col = lane & 15, row = 4*(lane>>4) + q
+                const float nai = sqrtf(red_sa[0][row] + red_sa[1][row] + red_sa[2][row] + red_sa[3][row]);
+                const int i = i0 + row, j = (c0 + t) * 16 + r;
+                if (i < na && j < nb) out[(int64_t)i * nb + j] = sum[q] / (nai * nbj);
+            }
+        }
+        __syncthreads();                                       // the next pass reuses the LDS
+    }
+}
+
+
 // Cosine of every (a_i, b_j) pair IN THE DTYPE OF THE EMBEDDINGS, i.e. with the roundings of the reference's
 // tensor expression  (e1 @ e2.T) / (e1.norm() * e2.norm().T)  (compute_clip_similarity R:109-114): each of the
 // four tensor ops rounds its result to the embedding dtype.  The class threshold of the refinement is an order
@@ -122,6 +209,11 @@ static int launch_cosine_gemm(const void *a, int32_t na, const void *b, int32_t 
     BFF_REQUIRE(dim % 32 == 0, "%s: dim must be a multiple of 32", what);
     if (na == 0 || nb == 0) return BFF_OK;
     BFF_REQUIRE(a && b && cos, "%s: null pointer", what);
+    if (nb > 64) {                                             // wide bank: A read once, k split over the block's waves
+        cosine_gemm_f16_rows_kernel<<<(unsigned)ceil_div(na, 16), 256, 0, as_stream(stream)>>>(
+            (const _Float16 *)a, na, (const _Float16 *)b, nb, dim, cos, norm_b);
+        return launched(what);
+    }
     dim3 grid((unsigned)ceil_div(ceil_div(nb, 16), 4), (unsigned)ceil_div(na, 16));
     cosine_gemm_f16_kernel<<<grid, 256, 0, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b, nb, dim, cos, norm_b);
     return launched(what);
