@@ -35,7 +35,8 @@ def bits(rows, n):
 
 def test_c4_checksums_layout_and_sweeps(c4):
     """(a) every set instance bit is one vote: sum of row popcounts == sum of masked_count; (b) Morton-sorted
-    layout == the caller's point order; (c) one fused sweep == a mask sweep + a separate viewed sweep."""
+    layout == the caller's point order; (c) one fused sweep == a mask sweep + a separate viewed sweep; (d) the
+    one-call path == the step-by-step path."""
     from beyond_fixed_forms_amd import _lib
     from beyond_fixed_forms_amd.projection import run_projection
     from beyond_fixed_forms_amd.scene import prepare_scene
@@ -47,6 +48,12 @@ def test_c4_checksums_layout_and_sweeps(c4):
     assert int(viewed.max().item()) <= ds.n_viewed and int(masked.max().item()) <= ds.n_rows
     groups, out_rows, out_conf = list(res.groups), res.rows.clone(), res.conf.clone()
     del res
+    # (d) the one-call path (bff_scene_project: label / word segments with 64-bit words, groups, overlaps and filters
+    # on the device) gives the same stage-2 result as the step-by-step path above
+    fast = run_projection(ds, cfg)
+    assert fast.debug["path"].startswith("fast"), fast.debug["path"]
+    assert torch.equal(fast.rows, out_rows) and torch.equal(fast.conf, out_conf) and list(fast.groups) == groups
+    del fast
     ds_plain = prepare_scene(scene, cfg, device=DEV, sort_points=False)
     res2 = run_projection(ds_plain, cfg, debug_out=True)
     assert torch.equal(res2.debug["raw_rows"], raw) and torch.equal(res2.debug["masked_counts_raw"], masked)
