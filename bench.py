@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 from beyond_fixed_forms_amd import _lib, distributed as bdist  # noqa: E402
 from beyond_fixed_forms_amd.config import Config  # noqa: E402
-from beyond_fixed_forms_amd.pipeline import PIPELINE_DEPTH  # noqa: E402
+from beyond_fixed_forms_amd.pipeline import PIPELINE_DEPTH, scene_streams  # noqa: E402
 from beyond_fixed_forms_amd.projection import projection_back, projection_front  # noqa: E402
 from beyond_fixed_forms_amd.refinement import TextSimilarity, prepare_stage1, refine_class  # noqa: E402
 from beyond_fixed_forms_amd.scene import prepare_scene  # noqa: E402
@@ -350,7 +350,7 @@ def main():
 
     timers = KernelTimers(reserve=4 * args.steps)      # events are created before the clock starts
     depth = max(2, args.depth)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    streams = scene_streams(dev, depth)
     host = {"front_issue_s": 0.0, "back_s": 0.0}     # host wall time per half (back includes its sync wait)
     results = {}
 

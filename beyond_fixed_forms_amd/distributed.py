@@ -218,9 +218,9 @@ def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[floa
     with_viewed = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
     # software pipeline over PIPELINE_DEPTH HIP streams: the device work of the next scenes is issued before the host
     # finishes scene k
-    from .pipeline import PIPELINE_DEPTH as depth
+    from .pipeline import PIPELINE_DEPTH as depth, scene_streams
     on_gpu = torch.device(device).type == "cuda"
-    streams = [torch.cuda.Stream(device=device) for _ in range(depth)] if on_gpu else None
+    streams = scene_streams(device) if on_gpu else None      # the same streams (and workspaces) for every class
 
     def front(k):
         sc = scenes[mine[k]]

@@ -339,7 +339,8 @@ def bench_host_inclusive(scenes, cfg, device, query, sim, steps=40, n_loaders=4,
                              for f, d in sc.depths.items()}
         host.append(sc)
     ing = Ingestor(cfg, device, n_loaders=n_loaders, native_threads=native_threads)
-    streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+    from .pipeline import scene_streams
+    streams = scene_streams(device)[:2]
     lookahead = n_loaders + 1
 
     def run(k):

@@ -57,6 +57,22 @@ class WorkspaceStruct(ctypes.Structure):
 # issues and collects every scene, and the chip are then both busy ~70 % of the time).
 PIPELINE_DEPTH = 4
 
+_scene_streams = {}
+
+
+def scene_streams(device, depth=None):
+    """The PIPELINE_DEPTH HIP streams scenes are issued on, created once per device: a SceneWorkspace (gigabytes) belongs
+    to a stream and lives as long as the process, so callers that run one class after the other must come back to the
+    same streams instead of creating new ones."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    depth = PIPELINE_DEPTH if depth is None else depth
+    have = _scene_streams.setdefault(idx, [])
+    while len(have) < depth:
+        have.append(torch.cuda.Stream(device=dev))
+    return have[:depth]
+
+
 _checked = False
 
 
