@@ -195,8 +195,9 @@ def label_plane_stride(n_pixels):
 
 
 def rle_to_labels(run_start, run_end, mask_run_offs, view_mask_offs, n_views, n_pixels, word_bits, labels, words, segmap):
-    """Segment-wise label bytes (uint8 [n_views][label_plane_stride(n_pixels)]) or mask words; segmap: int32
-    [n_views][2 * segmap_words(n_pixels)] (occupied | word form)."""
+    """Segment-wise palette blocks (uint8 [n_views][label_plane_stride(n_pixels)]: 64 B of 4-bit piece numbers + the
+    pieces' words per 128-pixel segment) or mask words; segmap: int32 [n_views][2 * segmap_words(n_pixels)] (occupied |
+    word form)."""
     call("bff_rle_to_labels", _ptr(run_start, i32), _ptr(run_end, i32), _ptr(mask_run_offs, i32),
          _ptr(view_mask_offs, i32), n_views, n_pixels, word_bits, _ptr(labels, u8),
          _ptr(words, torch.int32 if word_bits == 32 else torch.int64), _ptr(segmap, i32))

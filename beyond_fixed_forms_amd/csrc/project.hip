@@ -166,9 +166,12 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
         bool vis[kPPT];
         WordT wv[kPPT];
         if (kLabels) {
-            // segment by segment the decoder wrote either one label byte per pixel or the mask words (rle_to_maskbits_kernel
-            // <.., true>): one gather per point either way, both kinds in flight together
+            // segment by segment the decoder wrote either a palette block (4-bit index per pixel + the segment's distinct
+            // words, one 128-byte line) or the mask words (rle_to_maskbits_kernel<.., true>).  A point gathers its index
+            // byte or its word -- both kinds in flight together --, then the palette entry out of the line the index
+            // came from.
             uint32_t lb[kPPT];
+            bool pal_go[kPPT];
 #pragma unroll
             for (int j = 0; j < kPPT; ++j) {
                 vis[j] = (pix[j] >= 0) && (dval[j] != 0.0f) && (fabs(cz[j] - (double)dval[j]) < thresh);
@@ -177,12 +180,15 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
                 const bool words = (fbits[j] >> sb) & 1;
                 lb[j] = 0;
                 wv[j] = 0;
-                if (go && !words) lb[j] = limg[pix[j]];
+                pal_go[j] = go && !words;
+                if (go && !words) lb[j] = limg[(pix[j] & ~127) + ((pix[j] & 127) >> 1)];
                 if (go && words) wv[j] = mimg[pix[j]];
             }
 #pragma unroll
-            for (int j = 0; j < kPPT; ++j)
-                if (lb[j]) wv[j] = (WordT)1 << ((lb[j] - 1) & (sizeof(WordT) * 8 - 1));
+            for (int j = 0; j < kPPT; ++j) {
+                const uint32_t idx = (lb[j] >> (4 * (pix[j] & 1))) & 15u;
+                if (pal_go[j]) wv[j] = *reinterpret_cast<const WordT *>(limg + (pix[j] & ~127) + 64 + sizeof(WordT) * idx);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < kPPT; ++j) {
@@ -362,13 +368,15 @@ __device__ __forceinline__ uint64_t wave_xor_scan(uint64_t v)
 }
 
 // kLabels: every 128-pixel segment is written in ONE of two forms, chosen here segment by segment:
-//   label form  one BYTE per pixel in `labels` -- 0 = no mask, b in 1..64 = exactly mask b - 1 -- when no pixel of the
-//               segment lies in two masks (the segment is one 128-byte line of the label plane);
-//   word form   the mask words in `maskbits`, as without labels, when some pixel does.
+//   palette form  128 bytes in `labels` (the plane has one such block per segment): 64 bytes of 4-bit indices, one per
+//                 pixel, then the palette -- the words of the segment's PIECES (maximal runs of pixels with the same
+//                 word) in order, 16 of 32 bits or 8 of 64 bits -- so that pixel p's word is palette[index(p)].  Mask
+//                 words change only where a run of some mask starts or ends: a 128-pixel stretch of a row rarely has
+//                 more than a handful of pieces, whether masks overlap or not;
+//   word form     the mask words in `maskbits`, as without labels, when the segment has more pieces than that.
 // The segment bitmap then has TWO uint32 per 4096 pixels: [2k] = segment holds a mask pixel, [2k + 1] = segment is in
-// word form.  Masks of one view overlap on few pixels in real data (one mask per detected box), so most segments cost a
-// quarter (32 masks) or an eighth (64 masks) of the bytes to write -- the decoder is bound by its writes -- and to
-// gather; where masks do overlap nothing is lost against the plain word image, and the sweep never chases a pointer.
+// word form.  The decoder is bound by its writes and the sweep by the number of 128-byte lines it fetches: a palette
+// segment is ONE line instead of four (32-bit words) or eight.
 template <typename WordT, bool kLabels>
 __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
     const int32_t *__restrict__ run_start, const int32_t *__restrict__ run_end,
@@ -470,28 +478,43 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
             const int q = h * kHalf + lane * kQ;                     // word of the chunk
             bool as_labels = false;
             if (kLabels) {
-                static_assert(kQ == 4, "a lane's labels are one 32-bit store");
-                uint32_t packed = 0;
-                bool several = false;
-#pragma unroll
-                for (int k = 0; k < kQ; ++k) {
-                    const WordT w = outv[k];
-                    several |= (w & (w - 1)) != 0;
-                    const int first = (sizeof(WordT) == 8) ? __ffsll((unsigned long long)w) : __ffs((unsigned)w);   // 0 when empty
-                    packed |= (uint32_t)first << (8 * k);
-                }
-                const uint64_t sv = __ballot(several);
-                const uint32_t slo = (uint32_t)sv, sup = (uint32_t)(sv >> 32);
+                // Palette of the segment (= this half-wave's 128 words, 4 consecutive ones per lane): the words are piecewise
+                // constant along the row -- they change where a run of some mask starts or ends -- so the palette simply
+                // lists the PIECES in order (repeats allowed, the empty word included) and a pixel keeps the number of its
+                // piece: a transition flag per pixel, one 32-lane prefix sum, no loop.  More pieces than entries: word form.
+                static_assert(kQ == 4, "a lane's four palette indices are one 16-bit store");
+                constexpr int kPalMax = 64 / (int)sizeof(WordT);             // 16 entries of 32 bits / 8 of 64 bits
+                const int li = lane & 31;
+                const WordT prev = (sizeof(WordT) == 8) ? (WordT)__shfl_up((unsigned long long)outv[3], 1)
+                                                        : (WordT)__shfl_up((unsigned)outv[3], 1);
+                const int t0 = (li != 0 && outv[0] != prev) ? 1 : 0;         // pixel 0 of the segment opens piece 0
+                const int t1 = outv[1] != outv[0] ? 1 : 0, t2 = outv[2] != outv[1] ? 1 : 0, t3 = outv[3] != outv[2] ? 1 : 0;
+                const int cnt = t0 + t1 + t2 + t3;
+                int incl = cnt;                                              // inclusive prefix over the half's 32 lanes
+#define BFF_DPP_ADD(ctrl, rows) incl += __builtin_amdgcn_update_dpp(0, incl, ctrl, rows, 0xF, false)
+                BFF_DPP_ADD(0x111, 0xF);    // row_shr:1
+                BFF_DPP_ADD(0x112, 0xF);    // row_shr:2
+                BFF_DPP_ADD(0x114, 0xF);    // row_shr:4
+                BFF_DPP_ADD(0x118, 0xF);    // row_shr:8
+                BFF_DPP_ADD(0x142, 0xA);    // row_bcast:15 -> rows 1 and 3 (the second row of either half)
+#undef BFF_DPP_ADD
+                const int id0 = incl - cnt + t0, id1 = id0 + t1, id2 = id1 + t2, id3 = id2 + t3;
+                const int pieces_lo = __builtin_amdgcn_readlane(incl, 31) + 1, pieces_hi = __builtin_amdgcn_readlane(incl, 63) + 1;
+                const bool overflow = (lane < 32 ? pieces_lo : pieces_hi) > kPalMax;
+                const unsigned nib = (unsigned)id0 | ((unsigned)id1 << 4) | ((unsigned)id2 << 8) | ((unsigned)id3 << 12);
+                const uint64_t ov = __ballot(overflow);
+                const uint32_t slo = (uint32_t)ov, sup = (uint32_t)(ov >> 32);
                 fmt_bits |= ((slo ? 1u : 0u) | (sup ? 2u : 0u)) << (2 * h);
-                as_labels = (lane < 32 ? slo : sup) == 0;
-                if (store && as_labels) {
-                    if (whole || c0 + q + kQ <= c1) {                // label_stride and chunk starts are multiples of 4
-                        *reinterpret_cast<uint32_t *>(lab_c + q) = packed;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < kQ; ++k)
-                            if (c0 + q + k < c1) lab_c[q + k] = (uint8_t)(packed >> (8 * k));
-                    }
+                as_labels = !overflow;
+                const int seg0 = h * kHalf + (lane >> 5) * 128;          // first pixel of this half's segment in the chunk
+                if (store && as_labels && c0 + seg0 < c1) {              // the plane is padded to whole segments
+                    uint8_t *seg = lab_c + seg0;
+                    *reinterpret_cast<uint16_t *>(seg + 2 * li) = (uint16_t)nib;
+                    WordT *pal = reinterpret_cast<WordT *>(seg + 64);
+                    if (t0 || li == 0) pal[id0] = outv[0];                // the pixels that open a piece write its word
+                    if (t1) pal[id1] = outv[1];
+                    if (t2) pal[id2] = outv[2];
+                    if (t3) pal[id3] = outv[3];
                 }
             }
             if (store && !as_labels) {

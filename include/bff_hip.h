@@ -67,14 +67,19 @@ int bff_rle_to_maskbits(const int32_t *run_start, const int32_t *run_end, const 
                         void *maskbits, uint32_t *segmap, void *stream);
 
 /* The same decode, each 128-pixel segment written in the cheaper of two forms:
- *   label form  labels[v][p] (uint8, rows of bff_label_plane_stride(n_pixels) bytes) = 0 when pixel p of view v lies in
- *               no mask, b + 1 when it lies in mask view_mask_offs[v] + b -- when no pixel of the segment lies in two masks;
- *   word form   words[v][p] = the word of bff_rle_to_maskbits (same layout, same word_bits) -- when some pixel does.
+ *   palette form  one 128-byte block of `labels` (uint8, rows of bff_label_plane_stride(n_pixels) bytes; block s of view
+ *                 v = bytes [128 s, 128 s + 128) of its row): 64 bytes of 4-bit indices, pixel p's in byte (p mod 128) / 2,
+ *                 low nibble for even p; then the palette: the words of the segment's PIECES (maximal runs of pixels
+ *                 with the same word, the empty word included) in order -- 16 entries of 32 bits or 8 of 64 bits.  Pixel
+ *                 p's word is palette[index(p)].  Index bytes of pixels past the image edge are unspecified;
+ *   word form     words[v][p] = the word of bff_rle_to_maskbits (same layout, same word_bits) -- when the segment has
+ *                 more pieces than the palette holds.
  * segmap (required): uint32 [n_views][2 * ceil(ceil(n_pixels/128)/32)]: word 2k = "segment holds a mask pixel" for
  * segments 32k..32k+31 (others are not written at all), word 2k + 1 = "segment is in word form".  Only the plane a
- * segment's form names is written for it.  Masks of one view overlap on few pixels (one mask per detected box): the
- * decoder -- bound by its writes -- stores, and the sweep gathers from, a quarter (word_bits 32) or an eighth (64) of
- * the bytes, and a label segment is one 128-byte line.  labels must be 4-byte aligned, segmap 8-byte aligned. */
+ * segment's form names is written for it.  Mask words change only where a run of some mask starts or ends, so a
+ * 128-pixel stretch of a row has a handful of pieces whether masks overlap or not: the decoder -- bound by its writes --
+ * stores, and the sweep gathers from, ONE 128-byte line per segment instead of four (word_bits 32) or eight.
+ * labels must be 128-byte aligned, segmap 8-byte aligned. */
 int64_t bff_label_plane_stride(int64_t n_pixels);
 int bff_rle_to_labels(const int32_t *run_start, const int32_t *run_end, const int32_t *mask_run_offs,
                       const int32_t *view_mask_offs, int32_t n_views, int64_t n_pixels, int32_t word_bits,

@@ -63,8 +63,9 @@ def maskbits_from_dense(lib, masks_list, hw):
     assert np.array_equal(out2.cpu().numpy()[per_px], full[per_px]) and (out2.cpu().numpy()[~per_px] == -1).all()
     maskbits_from_dense.last_segmap = seg
     maskbits_from_dense.last_sparse = out2
-    # label / word segments: a 128-pixel segment without a pixel in two masks is written as one byte per pixel (0 none,
-    # b + 1 = mask b) into the label plane, any other as words into the word plane; nothing else is written
+    # palette / word segments: a 128-pixel segment with at most 16 (32-bit words) / 8 (64-bit) PIECES -- maximal runs of
+    # pixels with the same word -- is ONE 128-byte block of the label plane: 64 bytes of 4-bit piece numbers, then the
+    # pieces' words in order; any other occupied segment is written as words into the word plane; nothing else is written
     ls = lib.label_plane_stride(hw)
     assert ls == lib.load().bff_label_plane_stride(hw) and ls % 128 == 0 and 0 <= ls - hw < 128
     lab = torch.full((len(masks_list), ls), 0xEE, dtype=torch.uint8, device=DEV)
@@ -72,20 +73,35 @@ def maskbits_from_dense(lib, masks_list, hw):
     seg3 = torch.empty((len(masks_list), 2 * lib.segmap_words(hw)), dtype=torch.int32, device=DEV)
     lib.rle_to_labels(t(rs), t(re), t(offs), t(voffs), len(masks_list), hw, wb, lab, ovf, seg3)
     assert torch.equal(seg3[:, 0::2], seg)
-    fu = full.astype(np.uint64 if wb == 64 else np.uint32).astype(np.uint64)
-    several = (fu & (fu - np.uint64(1))) != 0
-    low = fu & (~fu + np.uint64(1))                                    # lowest set bit
-    first = np.where(fu != 0, np.log2(np.maximum(low, 1).astype(np.float64)).astype(np.int64) + 1, 0).astype(np.uint8)
     n_seg = (hw + 127) // 128
-    seg_several = np.stack([np.add.reduceat(several[v].astype(np.int64), np.arange(0, hw, 128)) > 0 for v in range(len(masks_list))])
+    pal_max, wdt = (16, np.uint32) if wb == 32 else (8, np.uint64)
     fmt = np.unpackbits(seg3[:, 1::2].contiguous().cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[:, :n_seg].astype(bool)
-    assert np.array_equal(fmt, seg_several)
-    as_words = np.repeat(fmt, 128, axis=1)[:, :hw]
     got_lab, got_ovf = lab.cpu().numpy(), ovf.cpu().numpy()
-    in_lab = per_px & ~as_words
-    assert np.array_equal(got_lab[:, :hw][in_lab], first[in_lab]) and (got_lab[:, :hw][~in_lab] == 0xEE).all()
-    assert (got_lab[:, hw:] == 0xEE).all()
-    assert np.array_equal(got_ovf[as_words], full[as_words]) and (got_ovf[~as_words] == -1).all()
+    fu = full.astype(np.uint64 if wb == 64 else np.uint32)
+    for v in range(len(masks_list)):
+        for sg in range(n_seg):
+            real = fu[v, sg * 128:min(hw, sg * 128 + 128)]               # index bytes past the image edge are unspecified
+            words = real
+            starts = np.flatnonzero(np.concatenate([[True], words[1:] != words[:-1]]))
+            piece_of = np.cumsum(np.concatenate([[0], (words[1:] != words[:-1]).astype(np.int64)]))
+            block = got_lab[v, sg * 128:sg * 128 + 128]
+            occupied = bool((real != 0).any())
+            assert bool(bits[v, sg]) == occupied
+            assert bool(fmt[v, sg]) == (occupied and starts.size > pal_max), (v, sg, starts.size)
+            if not occupied or fmt[v, sg]:
+                assert (block == 0xEE).all(), (v, sg)                    # no palette block for empty / word segments
+                if fmt[v, sg]:
+                    assert np.array_equal(got_ovf[v, sg * 128:sg * 128 + real.size].view(wdt), real)
+                else:
+                    assert (got_ovf[v, sg * 128:sg * 128 + real.size] == -1).all()
+                continue
+            assert (got_ovf[v, sg * 128:sg * 128 + real.size] == -1).all()
+            idx = np.stack([block[:64] & 15, block[:64] >> 4], axis=1).reshape(-1)
+            pal = block[64:].view(wdt)
+            assert np.array_equal(idx[:real.size], piece_of), (v, sg)
+            assert np.array_equal(pal[:starts.size], words[starts]), (v, sg)
+            assert (block[64 + starts.size * pal.itemsize:] == 0xEE).all()
+    assert (got_lab[:, n_seg * 128:] == 0xEE).all()
     maskbits_from_dense.last_labels_segmap = seg3
     maskbits_from_dense.last_labels = (lab, ovf)
     return out, wb
