@@ -147,6 +147,7 @@ class SceneWorkspace:
         self.in_flight = False
         self.rows_dirty = False
         self.both_primed = 0
+        self._fit_key = None
 
     @classmethod
     def for_current_stream(cls, device):
@@ -170,10 +171,14 @@ class SceneWorkspace:
 
     def fit(self, ds, s1_rows):
         """Make every buffer large enough for scene `ds` (+ s1_rows stage-1 masks)."""
-        lib = _lib.load()
         n, nw, n_rows = ds.n_points, ds.nw, ds.n_rows
         hw = ds.height * ds.width
         n_mviews = ds.view_mask_offs.shape[0] - 1
+        key = (n, nw, n_rows, hw, n_mviews, ds.word_bits, s1_rows)
+        if key == self._fit_key:                      # same sizes as the last scene on this stream: nothing to check
+            return self
+        self._fit_key = key
+        lib = _lib.load()
         mw = max(lib.bff_chunk_mask_words(nw), 1)
         nt = (n_rows + 63) // 64
         i32, i64, f32 = torch.int32, torch.int64, torch.float32
