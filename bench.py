@@ -212,12 +212,12 @@ def bench_cosine(args):
         "config": {"workload": "c5: 9000 x 768 f16 features against a 200 x 768 f16 bank, f32 accumulate + normalise"},
         "roofline": {"bound": "mfma", "kernel": "cosine_gemm_f16_kernel", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None,
-                     "note": "2.8 GFLOP per launch (SURVEY section 8d).  One block per 16 rows of A, k split over its 4 waves, every "
-                             "wave against all 13 column tiles: A (13.8 MB) is read once, the bank (0.3 MB) by every block out of "
-                             "L2.  563 blocks x 4 waves is half a wave per SIMD slot: the kernel is bound by the latency of its 6 "
-                             "rounds of 14 fragment loads per wave, not by MFMA issue (SQ counters: 43 % parked, 34 % issue stalls, "
-                             "23 % active).  The one-wave-per-tile kernel it replaces for wide banks re-read A for each column "
-                             "tile: 52-60 us"},
+                     "note": "2.8 GFLOP per launch (SURVEY section 8d).  One block per 64 rows of A, a wave per 16 rows against all "
+                             "13 column tiles; the bank's 32-k slices are staged once per block in LDS (double buffered, next slice "
+                             "in registers while the current one is multiplied); A is read once, the bank 141 times out of L2.  141 "
+                             "blocks on 256 CUs, one block per CU: the step time (1.1 us per 32 k) follows the bytes staged per "
+                             "block, not MFMA issue (13 MFMAs = 0.1-0.2 us).  Earlier forms: one wave per 16x16 tile 52-60 us "
+                             "(A re-read per column tile), k split over a block's waves 45 us"},
         "max_abs_err_vs_f64": err}))
 
 

@@ -160,6 +160,120 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_rows_kernel(const _Float1
 }
 
 
+// Many rows against a wide bank (config 5: 9000 x 768 against 200 x 768): one block per 64 rows of A, wave w owns rows
+// 16 w .. 16 w + 15 against ALL column tiles (13 per pass) over the whole k range.  The bank's k-slice of a step
+// (208 columns x 32 k = 13 KB) is staged ONCE per block in LDS and read by all four waves -- double buffered, the next
+// slice travelling global -> registers while the current one is multiplied, one barrier per step --, A is read once
+// (each wave prefetches its next fragment), the bank 141 times out of L2 (43 MB) instead of once per 16 rows.
+constexpr int kSK = 32;                                       // k per staged slice (64 = two MFMA k-steps per barrier was measured:
+                                                              // 28.4 vs 26.5 us -- the time follows the bytes staged per block)
+constexpr int kBPitch = kSK + 8;                              // halves per staged column (+16 B: the 16 columns of a tile
+                                                              // spread over the banks for ds_read_b128)
+__global__ __launch_bounds__(256) void cosine_gemm_f16_tile64_kernel(const _Float16 *__restrict__ a, int na,
+                                                                      const _Float16 *__restrict__ b, int nb, int dim,
+                                                                      float *__restrict__ out, int norm_b)
+{
+    __shared__ _Float16 sB[2][kCT * 16][kBPitch];             // 2 x 208 x 80 B = 33 KB
+    __shared__ float col_sq[kCT * 16];
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int r = lane & 15, kq = lane >> 4;                  // fragment: row/col r, k = 8*kq .. 8*kq+7
+    const int i0 = blockIdx.x * 64 + wave * 16;
+    const bool ra = i0 + r < na;
+    const _Float16 *a_row = a + (int64_t)(ra ? i0 + r : 0) * dim + 8 * kq;
+    const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int steps = (dim + kSK - 1) / kSK;                  // dim is a multiple of 32: the last slice may be half full
+    const int n_ct = (nb + 15) / 16;
+    constexpr int kParts = kSK / 8;                           // 16-byte pieces per staged column
+    constexpr int kPieces = kCT * 16 * kParts;
+    constexpr int kSlots = (kPieces + 255) / 256;
+    for (int c0 = 0; c0 < n_ct; c0 += kCT) {                  // block-uniform
+        float4v acc[kCT];
+#pragma unroll
+        for (int t = 0; t < kCT; ++t) acc[t] = float4v{0.f, 0.f, 0.f, 0.f};
+        float sa = 0.f, sq[kSlots];
+        const _Float16 *src[kSlots];                          // this thread's pieces: fixed (column, part) for all steps
+#pragma unroll
+        for (int q = 0; q < kSlots; ++q) {
+            const int p = tid + 256 * q, col = p / kParts, j = c0 * 16 + col;
+            sq[q] = 0.f;
+            src[q] = (p < kPieces && j < nb) ? b + (int64_t)j * dim + 8 * (p % kParts) : nullptr;
+        }
+        half8 piece[kSlots];
+        auto fetch = [&](int st) {
+#pragma unroll
+            for (int q = 0; q < kSlots; ++q) {
+                const int p = tid + 256 * q;
+                const bool kin = kSK * st + 8 * (p % kParts) < dim;
+                piece[q] = (src[q] && kin) ? *reinterpret_cast<const half8 *>(src[q] + kSK * st) : zero;
+            }
+        };
+        auto stage = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < kSlots; ++q) {
+                const int p = tid + 256 * q;
+                if (p < kPieces) *reinterpret_cast<half8 *>(&sB[buf][p / kParts][8 * (p % kParts)]) = piece[q];
+                if (norm_b) sq[q] = sumsq8(piece[q], sq[q]);
+            }
+        };
+        auto load_a = [&](int st, half8 (&f)[kSK / 32]) {
+#pragma unroll
+            for (int u = 0; u < kSK / 32; ++u)
+                f[u] = (ra && kSK * st + 32 * u < dim) ? *reinterpret_cast<const half8 *>(a_row + kSK * st + 32 * u) : zero;
+        };
+        half8 fa[kSK / 32], fa_next[kSK / 32];
+        fetch(0);
+        load_a(0, fa);
+        stage(0);
+        __syncthreads();
+        int cur = 0;
+        for (int st = 0; st < steps; ++st) {
+            if (st + 1 < steps) {                              // the next slice and A fragments travel while this one is multiplied
+                fetch(st + 1);
+                load_a(st + 1, fa_next);
+            }
+#pragma unroll
+            for (int u = 0; u < kSK / 32; ++u) {
+                sa = sumsq8(fa[u], sa);
+#pragma unroll
+                for (int t = 0; t < kCT; ++t) {
+                    const half8 fb = *reinterpret_cast<const half8 *>(&sB[cur][t * 16 + r][32 * u + 8 * kq]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u], fb, acc[t], 0, 0, 0);
+                }
+            }
+            if (st + 1 < steps) stage(cur ^ 1);                // the other buffer: its readers finished before the last barrier
+            __syncthreads();
+            cur ^= 1;
+#pragma unroll
+            for (int u = 0; u < kSK / 32; ++u) fa[u] = fa_next[u];
+        }
+        // squared norms: rows live in lanes r, r+16, r+32, r+48 of their own wave; a column's kParts pieces are
+        // neighbouring threads of one slot
+        sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);
+#pragma unroll
+        for (int q = 0; q < kSlots; ++q) {
+            float v = sq[q];
+#pragma unroll
+            for (int d = 1; d < kParts; d <<= 1) v += __shfl_xor(v, d);
+            const int p = tid + 256 * q;
+            if (p < kPieces && (p % kParts) == 0) col_sq[p / kParts] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kCT; ++t) {
+            if (c0 + t >= n_ct) continue;
+            const float nbj = norm_b ? sqrtf(col_sq[t * 16 + r]) : 1.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = kq * 4 + q;                    // C/D map: col = lane & 15, row = 4*(lane>>4) + q
+                const float nai = sqrtf(__shfl(sa, row));
+                const int i = i0 + row, j = (c0 + t) * 16 + r;
+                if (i < na && j < nb) out[(int64_t)i * nb + j] = acc[t][q] / (nai * nbj);
+            }
+        }
+        __syncthreads();                                       // col_sq and the buffers are reused by the next pass
+    }
+}
+
 // Cosine of every (a_i, b_j) pair IN THE DTYPE OF THE EMBEDDINGS, i.e. with the roundings of the reference's
 // tensor expression  (e1 @ e2.T) / (e1.norm() * e2.norm().T)  (compute_clip_similarity R:109-114): each of the
 // four tensor ops rounds its result to the embedding dtype.  The class threshold of the refinement is an order
@@ -209,6 +323,11 @@ static int launch_cosine_gemm(const void *a, int32_t na, const void *b, int32_t 
     BFF_REQUIRE(dim % 32 == 0, "%s: dim must be a multiple of 32", what);
     if (na == 0 || nb == 0) return BFF_OK;
     BFF_REQUIRE(a && b && cos, "%s: null pointer", what);
+    if (nb > 64 && na >= 2048) {                               // many rows, wide bank: the bank's k-slices through LDS
+        cosine_gemm_f16_tile64_kernel<<<(unsigned)ceil_div(na, 64), 256, 0, as_stream(stream)>>>(
+            (const _Float16 *)a, na, (const _Float16 *)b, nb, dim, cos, norm_b);
+        return launched(what);
+    }
     if (nb > 64) {                                             // wide bank: A read once, k split over the block's waves
         cosine_gemm_f16_rows_kernel<<<(unsigned)ceil_div(na, 16), 256, 0, as_stream(stream)>>>(
             (const _Float16 *)a, na, (const _Float16 *)b, nb, dim, cos, norm_b);

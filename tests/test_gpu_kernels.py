@@ -606,7 +606,9 @@ def test_depth_ingestion_matches_host_restatement(lib, hs, ws, h, w):
 # banks wider than 64 columns take the row-tile kernel (k split over 4 waves, 13 column tiles per pass): cover fewer
 # k-steps than waves (dim 64, 96), a ragged last column tile, a second pass (nb > 208) and ragged rows
 @pytest.mark.parametrize("na,nb,dim", [(1, 198, 768), (37, 200, 64), (300, 198, 512), (16, 16, 32), (50, 65, 96),
-                                       (33, 250, 160), (100, 431, 768)])
+                                       (33, 250, 160), (100, 431, 768),
+                                       # >= 2048 rows against a wide bank: 64-row blocks, the bank's k-slices through LDS
+                                       (2100, 198, 768), (2048, 250, 96), (2500, 70, 32)])
 def test_cosine_gemm(lib, na, nb, dim):
     """Config 5: CLIP-sized embeddings against a 200-label bank; |cos - f64 reference| <= 1e-4."""
     g = torch.Generator().manual_seed(na * dim)
