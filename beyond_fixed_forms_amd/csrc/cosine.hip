@@ -234,11 +234,13 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_tile64_kernel(const _Floa
 #pragma unroll
             for (int u = 0; u < kSK / 32; ++u) {
                 sa = sumsq8(fa[u], sa);
+                half8 fb[kCT];                                 // all 13 fragments in flight, then the MFMAs: read two by two
+#pragma unroll                                                 // (what the compiler does with one temporary) a k-step pays the
+                for (int t = 0; t < kCT; ++t)                  // LDS latency seven times
+                    fb[t] = *reinterpret_cast<const half8 *>(&sB[cur][t * 16 + r][32 * u + 8 * kq]);
+                __builtin_amdgcn_sched_barrier(0);             // keep the scheduler from sinking the reads between the MFMAs
 #pragma unroll
-                for (int t = 0; t < kCT; ++t) {
-                    const half8 fb = *reinterpret_cast<const half8 *>(&sB[cur][t * 16 + r][32 * u + 8 * kq]);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u], fb, acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < kCT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u], fb[t], acc[t], 0, 0, 0);
             }
             if (st + 1 < steps) stage(cur ^ 1);                // the other buffer: its readers finished before the last barrier
             __syncthreads();
