@@ -1,5 +1,7 @@
-"""Where merge_components spends its block time at config 2 / 4: cycle counters per phase (diag mode)."""
+"""Phase clocks of the components' tile pass (diagnostic build of the kernel, BFF_MERGE_DIAG=1: thread 0 of every block
+adds the cycles of each phase; 2 blocks per CU instead of 3).  usage: python scripts/diag_merge_phases.py [c2|c4] [default|many]"""
 import os, sys
+os.environ["BFF_MERGE_DIAG"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from beyond_fixed_forms_amd import _lib
@@ -10,40 +12,22 @@ from beyond_fixed_forms_amd.synthetic import make_scene
 _lib.load()
 dev = "cuda"
 shape = sys.argv[1] if len(sys.argv) > 1 else "c2"
-scene = make_scene(shape, seed=0, device=dev, query="table")
+kind = sys.argv[2] if len(sys.argv) > 2 else "default"
+var = dict(cut_masks=False, n_objects=40, distinct_masks=True, dilate=False) if kind == "many" else {}
+scene = make_scene(shape, seed=0, device=dev, query="table", **var)
 cfg = Config.with_defaults(width_2d=scene.width, height_2d=scene.height)
 ds = prepare_scene(scene, cfg, device=dev)
-fr = projection_front(ds, cfg, debug_out=True)
-rows = fr.rows
-area, mw_, cmask, hist, sig = _lib.row_stats(rows)
-order = _lib.argsort_i64(sig, 30)
-names = ["tiles", "chunk visits", "candidate pairs", "unions", "roots+hist staging", "pair bounds", "lists", "pair-list pass",
-         "dense pass", "tiles via pair list", "tiles via dense pass"]
-for label, parent in (("from scratch", None), ("from the converged forest", "conv")):
-    if parent == "conv":
-        parent = _lib.merge_components(rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist).clone()
-    cap = 40000
-    d = torch.zeros(16 + 2 * cap, dtype=torch.int32, device=dev)
-    d[15] = cap
-    _lib.merge_components(rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist, diag=d, parent=parent)
-    v = d[:16].tolist()
-    tl = d[16:16 + 2 * cap].view(-1, 2).cpu().numpy().astype("int64") & 0xffffffff
-    tl = tl[(tl[:, 1] != 0)]
-    t0 = tl[:, 0].min()
-    st, en = (tl[:, 0] - t0) * 0.01, (tl[:, 1] - t0) * 0.01                        # us (100 MHz ticks)
-    import numpy as np
-    span = en.max()
-    grid = np.linspace(0, span, 41)
-    conc = [(int(((st <= g) & (en > g)).sum())) for g in grid]
-    dur = en - st
-    print(f"  blocks with work {len(st)}, kernel span {span:.0f} us, block duration mean {dur.mean():.1f} / p50 {np.median(dur):.1f} / p90 {np.percentile(dur, 90):.1f} / max {dur.max():.1f} us")
-    print("  running blocks over time (40 samples):", conc)
-    print(f"\n{shape} {label}:")
-    for k in range(4):
-        print(f"  {names[k]:24s} {v[k]}")
-    for k in (9, 10):
-        print(f"  {names[k]:24s} {v[k]}")
-    tot = sum(v[4:9])
-    for k in range(4, 9):
-        cyc = v[k] * 64
-        print(f"  {names[k]:24s} {cyc / 2.4e3 / 1e3:9.1f} ms of block time  ({100.0 * v[k] / max(1, tot):5.1f} %)   -> / 768 resident blocks = {cyc / 2.4e3 / 768:7.1f} us")
+fr = projection_front(ds, cfg, fast=False)
+area, _mw, cmask, hist, sig = _lib.row_stats(fr.rows, fr.cmask)
+order = _lib.argsort_i64(sig, _lib.SIGNATURE_BITS)
+for rep in range(2):
+    d = torch.zeros(16, dtype=torch.int32, device=dev)
+    _lib.merge_components(fr.rows, area, ds.label_id, cfg.iou_thres, order, cmask, hist, diag=d)
+v = d.cpu().tolist()
+names = {4: "rows, roots, histogram staging", 5: "per-pair histogram bound", 11: "chunk-level bound", 6: "pair / chunk lists",
+         7: "pair-list pass (incl. its unions)", 8: "4x4-block pass (incl. its unions)"}
+tot = sum(v[k] for k in names)
+print(f"{shape} {kind}: tile pairs at the exact stage {v[0]}, chunk visits {v[1]}, candidate pairs {v[2]}, unions {v[3]}, "
+      f"blocks on the pair-list path {v[9]}, on the 4x4 path {v[10]}")
+for k, n in names.items():
+    print(f"  {n:38s} {v[k] * 64 / 1e6:9.1f} Mcycles  {100.0 * v[k] / max(tot, 1):5.1f} %")
