@@ -98,7 +98,7 @@ int bff_rle_to_labels(const int32_t *run_start, const int32_t *run_end, const in
  *   cam_intr     float64 [9] row-major K (HOST pointer; copied into kernel arguments)
  *   depth        float32 [n_depth][H*W] metres; frame f uses image depth_index[f]
  *   maskbits     mask words of bff_rle_to_maskbits, or -- with `labels` -- the word plane of bff_rle_to_labels
- *   labels       label plane of bff_rle_to_labels (then maskbits and segmap are its companions) or NULL
+ *   labels       palette plane of bff_rle_to_labels (then maskbits and segmap are its companions) or NULL
  *   segmap       the decoder's segment bitmap (see bff_rle_to_maskbits) or NULL
  *   frame_mask   int32 [n_frames]: index of the frame's mask-word image in `maskbits`, or -1
  *   frame_rowbase int32 [n_frames]: first instance row of the frame (row = rowbase + bit)
@@ -485,7 +485,7 @@ typedef struct bff_scene_params {
  * clears them with a single fill. */
 typedef struct bff_scene_workspace {
     void *maskbits; uint32_t *segmap;  /* word plane and two-word segment bitmap of bff_rle_to_labels */
-    uint8_t *labels;                /* [n_mviews][bff_label_plane_stride(H*W)] */
+    uint8_t *labels;                /* palette blocks, [n_mviews][bff_label_plane_stride(H*W)] */
     uint64_t *rows, *chunk_mask, *keep, *tile_mask, *agg, *both;
     int32_t *masked, *viewed, *sel_scratch, *area, *mean_word, *order, *parent, *comp, *count;
     int32_t *gmembers, *goffs, *slices, *inter;
@@ -539,7 +539,7 @@ int bff_cloud_layout(const double *pts, int64_t n, int64_t stride, int64_t n_pad
 /* Measurement aid: the 128-byte lines of the depth and mask-word images that one sweep touches, as bitmaps (uint32
  * [n_frames][line_words], zeroed by the caller; line index = pixel / (pixels per 128 B)).  128 B per marked line is
  * the sweep's compulsory HBM traffic for these images (bench.py: roofline.compulsory).  label_lines != NULL: segmap is
- * bff_rle_to_labels' two-word bitmap; segments in label form mark label_lines (128 pixels per line) instead. */
+ * bff_rle_to_labels' two-word bitmap; segments in palette form mark label_lines (128 pixels per line) instead. */
 int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
                          const double *cam_intr_host, int32_t n_frames, const float *depth, const int32_t *depth_index,
                          int32_t height, int32_t width, double depth_thresh, const uint32_t *segmap, int32_t word_bits,
