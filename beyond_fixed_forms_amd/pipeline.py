@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time
 from ctypes import c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 import numpy as np
@@ -57,6 +58,7 @@ class WorkspaceStruct(ctypes.Structure):
 # issues and collects every scene, and the chip are then both busy ~70 % of the time).
 PIPELINE_DEPTH = 4
 
+_TRACE_ISSUE = bool(os.environ.get("BFF_TRACE_ISSUE"))       # report scene calls that take more than 2 ms to enqueue
 _scene_streams = {}
 
 
@@ -239,10 +241,7 @@ class SceneWorkspace:
 
 def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
     """Enqueue the whole device side of one scene on the current stream.  Returns a handle for `collect`."""
-    import time as _time
-    _t0 = _time.perf_counter()
-    _marks = []
-    _mark = lambda name: _marks.append((name, round((_time.perf_counter() - _t0) * 1e3, 3)))
+    t0 = time.perf_counter() if _TRACE_ISSUE else 0.0
     dev = ds.xyz.device
     key = (id(stage1), n_frames)
     cache = ds.__dict__.setdefault("_scene_structs", {})
@@ -251,9 +250,7 @@ def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
         ent = cache[key] = (scene_struct(ds, stage1, n_frames), stage1)      # keeps stage1's tensors alive too
     sc = ent[0]
     s1_rows = int(sc.s1_rows)
-    _mark("struct")
     ws = SceneWorkspace.for_current_stream(dev).fit(ds, s1_rows)
-    _mark("fit")
     if ws.in_flight or ws.rows_dirty:             # a call whose results were never collected: the arena may be dirty
         ws.t["rows"].zero_()
         ws.rows_dirty = False
@@ -272,19 +269,18 @@ def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
     use_sort = os.environ.get("BFF_FILTER_SET") != "1" or bool(ds.__dict__.get("_filter_sort", False))
     pr = params_struct(cfg, depth_thresh, filter_sort=use_sort)
     ws.in_flight = True
-    _mark("both")
+    t1 = time.perf_counter() if _TRACE_ISSUE else 0.0
     _lib.call("bff_scene_project", ctypes.byref(sc), ctypes.byref(pr), ctypes.byref(ws.struct))
-    _mark("call")
-    if _marks[-1][1] > 2.0 and os.environ.get("BFF_TRACE_ISSUE"):
+    if _TRACE_ISSUE and time.perf_counter() - t0 > 2e-3:      # the one-time stalls of a process's first scene calls
         import sys
-        print("slow issue:", _marks, file=sys.stderr)
+        now = time.perf_counter()
+        print(f"slow issue: {1e3 * (now - t0):.2f} ms, of which the native call {1e3 * (now - t1):.2f} ms", file=sys.stderr)
     return dict(ws=ws, both=both, s1_rows=s1_rows, params=pr, stream=ws.stream,
                 args=(ds, cfg, depth_thresh, stage1, n_frames))
 
 
 def collect(h):
     """Wait for the header of `issue` and return it as an int32 array (a copy: the pinned buffer is reused)."""
-    import time
     t0 = time.perf_counter()
     h["stream"].synchronize()
     _lib.sync_wait_s += time.perf_counter() - t0
