@@ -132,31 +132,42 @@ def assign_instances_for_scan(preds, gts_sem, gts_ins, class_labels, use_label=T
         gt2pred = {eval_labels[0]: agnostic}
         cols = {eval_labels[0]: acols}
 
+    # ---- predictions that are large enough to count (:323-324), numbered in input order (:358-360)
     pred2gt = {lab: [] for lab in eval_labels}
-    num_pred_instances = 0
-    for r, k in enumerate(keep):                                                   # :309-363
-        pred = preds[k]
-        label_name = id2label[pred["label_id"]] if use_label else eval_labels[0]
-        num = int(pred_count[r])
-        if num < min_region:                                                       # :323-324
+    pred_count = np.asarray(pred_count, dtype=np.int64)
+    big = np.flatnonzero(pred_count >= min_region)
+    records, by_label = [], {lab: [] for lab in eval_labels}
+    for number, r in enumerate(big.tolist()):
+        pred = preds[keep[r]]
+        lab = id2label[pred["label_id"]] if use_label else eval_labels[0]
+        rec = {"filename": "{}_{}".format(pred["scan_id"], number), "pred_id": number,
+               "label_id": pred["label_id"] if use_label else None, "vert_count": int(pred_count[r]),
+               "confidence": pred["conf"], "void_intersection": int(void_inter[r])}
+        records.append(rec)
+        by_label[lab].append((r, len(records) - 1))
+    # ---- matches = the non-zero entries of the Gram block (predictions of a label) x (ground truth of that label);
+    # np.nonzero walks it row-major, i.e. prediction by prediction and within one by ground-truth position, the order
+    # in which the reference's nested loops meet them (:331-357).  IoU = I / (|gt| + |pred| - I) in float64 (:340)
+    matched = [[] for _ in records]
+    for lab, members in by_label.items():
+        gt_list = gt2pred[lab]
+        if not members or not gt_list:
             continue
-        pred_instance = {"filename": "{}_{}".format(pred["scan_id"], num_pred_instances), "pred_id": num_pred_instances,
-                         "label_id": pred["label_id"] if use_label else None, "vert_count": num,
-                         "confidence": pred["conf"], "void_intersection": int(void_inter[r])}
-        matched_gt = []
-        for gt_num, gt_inst in enumerate(gt2pred[label_name]):
-            intersection = int(inter[r, cols[label_name][gt_num]])
-            if intersection > 0:
-                gt_copy = gt_inst.copy()
-                pred_copy = pred_instance.copy()
-                gt_copy["intersection"] = intersection
-                pred_copy["intersection"] = intersection
-                iou = float(intersection) / (gt_copy["vert_count"] + pred_copy["vert_count"] - intersection)
-                gt_copy["iou"] = iou
-                pred_copy["iou"] = iou
-                matched_gt.append(gt_copy)
-                gt2pred[label_name][gt_num]["matched_pred"].append(pred_copy)
-        pred_instance["matched_gt"] = matched_gt
-        num_pred_instances += 1
-        pred2gt[label_name].append(pred_instance)
+        r_idx = np.array([m[0] for m in members])
+        block = np.asarray(inter, dtype=np.int64)[np.ix_(r_idx, np.asarray(cols[lab], dtype=np.int64))]
+        pi, gi = np.nonzero(block > 0)
+        hit = block[pi, gi]
+        gt_verts = np.array([g["vert_count"] for g in gt_list], dtype=np.int64)
+        iou = hit.astype(np.float64) / (gt_verts[gi] + pred_count[r_idx][pi] - hit).astype(np.float64)
+        for p_, g_, i_, u_ in zip(pi.tolist(), gi.tolist(), hit.tolist(), iou.tolist()):
+            rec_no = members[p_][1]
+            gt = gt_list[g_]
+            # the ground-truth side keeps a snapshot of the prediction as it is before its own matches are attached,
+            # the prediction side a shallow snapshot of the ground-truth entry (its match list stays the shared one)
+            gt["matched_pred"].append(dict(records[rec_no], intersection=i_, iou=u_))
+            matched[rec_no].append(dict(gt, intersection=i_, iou=u_))
+    for rec, m in zip(records, matched):
+        rec["matched_gt"] = m
+    for lab, members in by_label.items():
+        pred2gt[lab] = [records[k] for _, k in members]
     return gt2pred, pred2gt
