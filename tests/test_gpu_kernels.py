@@ -731,23 +731,31 @@ def test_cosine_golden_on_device(lib):
     e32 = torch.from_numpy(z["clip.emb_f32"][:, 0, :].copy())
     e16 = torch.from_numpy(z["clip.emb_f16"][:, 0, :].copy()).half()
     got32 = lib.cosine_rows(e32.to(DEV), e32.to(DEV)).cpu().numpy().astype(np.float64)
-    assert np.abs(got32 - z["clip.sims_f32"]).max() <= 1e-4              # north_star's tolerance
-    assert np.abs(got32 - z["clip.sims_f32"]).max() <= 5e-7              # observed: 2 float32 ulps at |cos| ~ 1 (dot, norms and their product each round once)
+    d32 = np.abs(got32 - z["clip.sims_f32"])
+    assert d32.max() <= 1e-4                                             # north_star's tolerance
+    # float32: bff_cosine_rows rounds the exact dot / norms once each (float64 accumulation), the reference's BLAS
+    # sdot and its vectorised norm accumulate in float32 in machine-dependent orders.  Everything agrees to one ulp
+    # of 1.0 (2^-23) except self-similarities: ours are exactly 1.0 (dot == norm^2 before rounding), the reference's
+    # own dot and norm disagree in the last bits (golden [3, 3] = 1 + 2^-22)
+    off = d32 > 2.0 ** -23
+    assert d32.max() <= 2.0 ** -22 and np.all(got32[off] == 1.0), (d32.max(), np.argwhere(off))
     got16 = lib.cosine_rows(e16.to(DEV), e16.to(DEV)).cpu().numpy().astype(np.float64)
     assert np.array_equal(got16, got16.astype(np.float16).astype(np.float64))       # float16 values
-    assert np.abs(got16 - z["clip.sims_f16"]).max() <= 2.0 ** -11        # one float16 ulp below 1.0
     assert got16[0, 0] == z["clip.sims_f16"][0, 0] == 0.99951171875      # the reference's self-similarity in fp16
     assert got16[0, 5] == got16[0, 0] and np.array_equal(got16[5], got16[0])        # equal embeddings tie
-    n_same = int((got16 == z["clip.sims_f16"]).sum())
-    assert n_same >= 34, n_same                                          # all but rounding-boundary cases identical
+    # float16: products of float16 values and their 64-term sums are exact in float64, so the kernel's value of every
+    # tensor op is the correctly rounded one -- bit-equal to the golden file on all 36 entries (checked against a NumPy
+    # restatement of the kernel's arithmetic when this assertion was tightened from ">= 34")
+    assert np.array_equal(got16, z["clip.sims_f16"]), np.argwhere(got16 != z["clip.sims_f16"])
     # MFMA GEMM on the same float16 embeddings (dim 64 = 2 k-steps): float32 normalisation
     pad = lambda x: x.to(DEV).contiguous()
     gemm = lib.cosine_gemm_f16(pad(e16), pad(e16)).cpu().numpy().astype(np.float64)
     e = e16.double()
     exact = ((e @ e.T) / (e.norm(dim=1, keepdim=True) * e.norm(dim=1, keepdim=True).T)).numpy()
     assert np.abs(gemm - exact).max() <= 1e-4
-    # the golden fp16 values carry four float16 roundings (dot, two norms, their product, the quotient): up to two
-    # float16 ulps (2^-10 below 1.0) away from the exact cosine the GEMM approximates
+    # a-priori bound, not an observed one: the golden fp16 values carry four float16 roundings (dot, norms, their
+    # product, the quotient) of half an ulp each (2^-12 relative below 1.0) = 2^-10 from the exact cosine, which the
+    # GEMM approximates within north_star's 1e-4
     assert np.abs(gemm - z["clip.sims_f16"]).max() <= 2.0 ** -10 + 1e-4
     # 9000 x 768 against a 200-label bank (BASELINE config 5 at full size), vs float64
     gen = torch.Generator().manual_seed(5)

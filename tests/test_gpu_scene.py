@@ -71,6 +71,21 @@ def test_golden_scene(api, name):
     for stage2 in (res, {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in res.to_dict().items()}):
         fin = refinement.refine_class([(scene.scene_id, scene.stage1, stage2)], cfg, "table", sim, DEV)
         check_golden(fin[scene.scene_id].to_dict(), z, "final", n)
+    # the PRODUCTION path against the same fixtures, directly: native ingestion (prepare_scene_fast) + the one-call
+    # device path (bff_scene_project) with the refinement's first pass riding along, as the CLI and bench.py run it
+    prod = projection.project_scene(scene, cfg, DEV, return_result=True, debug_out=False)
+    assert prod.debug["path"] == "fast"
+    assert prod.groups == gio.loads_groups(z["dbg.groups"])
+    assert np.array_equal(np.array(np.float32(prod.debug["thr"])).view(np.uint32), z["dbg.thr_bits"])
+    check_golden(prod.to_dict(), z, "stage2", n)
+    from beyond_fixed_forms_amd.ingest import prepare_scene_fast
+    st1 = refinement.prepare_stage1(scene.stage1, DEV)
+    ds = prepare_scene_fast(scene, cfg, DEV)
+    prod2 = projection.projection_back(projection.projection_front(ds, cfg, stage1=st1))
+    assert prod2.debug["path"] == "fast" and prod2.prefetch is not None
+    check_golden(prod2.to_dict(), z, "stage2", n)
+    fin = refinement.refine_class([(scene.scene_id, st1, prod2)], cfg, "table", sim, DEV)
+    check_golden(fin[scene.scene_id].to_dict(), z, "final", n)
 
 
 def test_golden_class_three_scenes(api):
