@@ -6,9 +6,12 @@
 A "step" is one pass of the hot path over one batch = ONE scene per GPU of BASELINE config 2
 (200k points x 300 views @968x1296, 30 masks/view, stage-1 S1=100, 768-d text bank): RLE decode ->
 fused projection sweep -> IoU/label adjacency -> components -> merge -> ratio filter -> overlap/size
-filters -> refinement (stage-1 RLE decode, cross IoU, MFMA cosine, final masks) -> gather of the final
-bit-packed masks on rank 0.  Inputs are resident in HBM (uploaded before the timed region) in the
-reference's formats: float64 cloud, float32 depth, RLE runs.  Scenes shard one per GPU (weak scaling).
+filters -> refinement pass 1 (stage-1 RLE decode, cross IoU, text cosines).  As in the reference, the
+refinement is per query CLASS (R:316-324: one similarity threshold over all scenes of the class): every
+`--class-batch` steps (default 8 scenes per GPU) the class is closed with ONE all-gather of the ranks'
+similarity sets, pass 2, and ONE gather of the final bit-packed masks on rank 0 -- inside the timed region.
+Inputs are resident in HBM (uploaded before the timed region) in the reference's formats: float64 cloud,
+float32 depth, RLE runs.  Scenes shard one per GPU (weak scaling); N = 1 runs the same loop without collectives.
 
 The JSON line also carries `roofline` for the HBM-bound projection sweep (HIP-event timed on the
 launch stream, live) and `cpu_baseline`: the oracle (CPU restatement of the reference) timed on a
@@ -41,9 +44,9 @@ sys.path.insert(0, ROOT)
 
 from beyond_fixed_forms_amd import _lib, distributed as bdist  # noqa: E402
 from beyond_fixed_forms_amd.config import Config  # noqa: E402
-from beyond_fixed_forms_amd.pipeline import PIPELINE_DEPTH, scene_streams  # noqa: E402
+from beyond_fixed_forms_amd.pipeline import PIPELINE_DEPTH, pipelined, scene_streams  # noqa: E402
 from beyond_fixed_forms_amd.projection import projection_back, projection_front  # noqa: E402
-from beyond_fixed_forms_amd.refinement import TextSimilarity, prepare_stage1, refine_class  # noqa: E402
+from beyond_fixed_forms_amd.refinement import TextSimilarity, prepare_stage1  # noqa: E402
 from beyond_fixed_forms_amd.scene import prepare_scene  # noqa: E402
 from beyond_fixed_forms_amd.synthetic import SHAPES, make_scene, make_text_bank  # noqa: E402
 from beyond_fixed_forms_amd.timing import KernelTimers  # noqa: E402
@@ -299,6 +302,8 @@ def main():
     ap.add_argument("--host-profile", action="store_true", help="cProfile of the timed loop to stderr")
     ap.add_argument("--depth", type=int, default=PIPELINE_DEPTH, help="scenes in flight on the device (one HIP stream each)")
     ap.add_argument("--scenes", type=int, default=4, help="resident scenes rotated through the timed loop")
+    ap.add_argument("--class-batch", type=int, default=8,
+                    help="scenes per GPU that form one query class: one similarity exchange + one gather per batch")
     ap.add_argument("--include-upload", action="store_true",
                     help="also report the host-inclusive rate: every step takes host arrays (reference formats, raw "
                          "16-bit depth) through the overlapped ingestion pipeline before the device path")
@@ -344,15 +349,16 @@ def main():
     enc = bank_encoder(bank, index)
     sim = TextSimilarity(enc, dev)
     t_setup = time.perf_counter() - t0
-    exchange = bdist.ClassExchange("cpu" if rehearse else dev) if world > 1 else None     # sims + result-size bounds, one all-gather
+    exchange = bdist.ClassExchange("cpu" if rehearse else dev) if world > 1 else None     # sims + result-size bounds, one all-gather per class
     if world > 1:
         dist.barrier()
 
     timers = KernelTimers(reserve=4 * args.steps)      # events are created before the clock starts
     depth = max(2, args.depth)
     streams = scene_streams(dev, depth)
-    host = {"front_issue_s": 0.0, "back_s": 0.0}     # host wall time per half (back includes its sync wait)
-    results = {}
+    cbatch = max(1, args.class_batch)
+    host = {"front_issue_s": 0.0, "back_s": 0.0, "class_finish_s": 0.0}     # host wall time per part (back includes its sync wait)
+    results, last_class = {}, {}
 
     trace_front = [] if os.environ.get("BFF_BENCH_TRACE_FRONT") else None
     def front(i, tm=None):
@@ -365,41 +371,39 @@ def main():
             trace_front.append(round((time.perf_counter() - t) * 1e3, 3))
         return fr
 
-    def back(i, fr):
-        t = time.perf_counter()
-        try:
-            return _back(i, fr)
-        finally:
+    def run_steps(k, tm=None):
+        """k scenes per rank, one after the other through the whole path, in query classes of `cbatch` scenes per rank.
+        Pipelined form: while the host works on the back half of scene i (header, size filter, refinement pass 1 --
+        and, at the end of a class, the exchange, pass 2 and the gather), the device work of scenes i+1 .. i+depth-1
+        already runs on the other streams; class boundaries do not drain the pipeline."""
+        cur = {"batch": None}
+
+        def back(i, fr):
+            t = time.perf_counter()
+            ks = i % n_scenes
+            j = i % cbatch
+            with torch.cuda.stream(streams[i % depth]):
+                res = projection_back(fr, want_groups=False)
+                if j == 0:
+                    nb = min(cbatch, k - i)             # scenes of this class on every rank
+                    ids = [f"r{r}s{q}" for r in range(world) for q in range(nb)]
+                    cur["batch"] = bdist.ClassBatch(cfg, QUERY, sim, dev, ids, nb, exchange=exchange)
+                    cur["n"] = nb
+                batch = cur["batch"]
+                batch.add(f"r{rank}s{j}", stage1s[ks], res)
+                results[ks] = [int(res.rows.shape[0]), None]
+                if j + 1 == cur["n"]:
+                    t1 = time.perf_counter()
+                    batch.finish()                      # ONE exchange, pass 2, ONE gather (rank 0 keeps the buffers)
+                    host["class_finish_s"] += time.perf_counter() - t1
+                    for q in range(cur["n"]):
+                        f = batch.final[f"r{rank}s{q}"]
+                        results[(i - cur["n"] + 1 + q) % n_scenes][1] = 0 if f.rows is None else int(f.rows.shape[0])
+                    last_class["batch"] = batch
             host["back_s"] += time.perf_counter() - t
 
-    def _back(i, fr):
-        k = i % n_scenes
-        with torch.cuda.stream(streams[i % depth]):
-            res = projection_back(fr, want_groups=False)
-            fin = refine_class([(scenes[k].scene_id, stage1s[k], res)], cfg, QUERY, sim, dev, exchange_sims=exchange)
-            rows = fin[scenes[k].scene_id].rows
-            if rows is None:
-                rows = torch.zeros((0, dss[k].nw), dtype=torch.int64, device=dev)
-            gathered = bdist.gather_final_rows(rows, bounds=exchange.bounds if exchange is not None else None)
-        results[k] = (int(res.rows.shape[0]), int(rows.shape[0]))
-        return res, fin, gathered
-
-    def run_steps(k, tm=None):
-        """k scenes, one after the other through the whole path.  Pipelined form: while the host works on the
-        back half of scene i (header, size filter, refinement bookkeeping), the device work of scene i+1 already
-        runs on the other stream."""
-        out = None
-        if args.no_pipeline:
-            for i in range(k):
-                out = back(i, front(i, tm))
-            return out
-        inflight, issued = [], 0
-        for i in range(k):
-            while issued < k and issued - i < depth:       # scenes i .. i + depth - 1 are on the device
-                inflight.append(front(issued, tm))
-                issued += 1
-            out = back(i, inflight.pop(0))
-        return out
+        for _ in pipelined(k, lambda i: front(i, tm), back, 1 if args.no_pipeline else depth):
+            pass
 
     # Priming (setup, not part of the W warm-up steps the contract asks for): the first ~14 scene calls of a process
     # include one-time costs -- a workspace per stream (~6 ms each) and three more calls that block ~6 ms inside the
@@ -416,8 +420,10 @@ def main():
             torch.cuda.synchronize()
 
     fence()
-    host.update(front_issue_s=0.0, back_s=0.0)
+    host.update(front_issue_s=0.0, back_s=0.0, class_finish_s=0.0)
     _lib.sync_wait_s = 0.0
+    if exchange is not None:
+        exchange.calls = 0
     prof = None
     if args.host_profile:                              # where the host thread's time goes (stderr; slows the loop)
         import cProfile
@@ -431,8 +437,10 @@ def main():
         import pstats
         prof.disable()
         pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(35)
+    n_exchanges = exchange.calls if exchange is not None else 0
     host_ms = {"front_issue": round(host["front_issue_s"] / args.steps * 1e3, 4),
                "back": round(host["back_s"] / args.steps * 1e3, 4),
+               "of_back_class_finish": round(host["class_finish_s"] / args.steps * 1e3, 4),
                "of_which_waiting_for_gpu": round(_lib.sync_wait_s / args.steps * 1e3, 4)}
     host_ms["host_work"] = round(host_ms["front_issue"] + host_ms["back"] - host_ms["of_which_waiting_for_gpu"], 4)
     if world > 1:
@@ -460,7 +468,8 @@ def main():
         e0.record(st)
         fr = front(k)
         e1.record(st)
-        back(k, fr)
+        with torch.cuda.stream(st):
+            projection_back(fr, want_groups=False)
         torch.cuda.synchronize()
         spans.append(round(e0.elapsed_time(e1), 4))
 
@@ -468,6 +477,20 @@ def main():
     if args.include_upload and rank == 0:
         from beyond_fixed_forms_amd.ingest import bench_host_inclusive
         upload_leg = bench_host_inclusive(scenes, cfg, dev, QUERY, sim, steps=min(args.steps, 40))
+
+    # what rank 0 holds after the last class: every rank's final masks, decoded from the gathered buffers only now
+    gathered_check = None
+    if last_class.get("batch") is not None:
+        lb = last_class["batch"]
+        got = lb.results()
+        if rank == 0:
+            own = {sid: f for sid, f in lb.final.items()}
+            same_own = all((got[sid].rows is None and f.rows is None) or
+                           (got[sid].rows is not None and f.rows is not None and torch.equal(got[sid].rows.to(dev), f.rows))
+                           for sid, f in own.items())
+            gathered_check = {"scenes_on_rank0": len(got), "expected": len(lb.ids), "rank0_rows_round_trip": bool(same_own),
+                              "final_masks_total": int(sum(0 if f.rows is None else f.rows.shape[0] for f in got.values()))}
+            assert len(got) == len(lb.ids) and same_own, gathered_check
 
     if trace_front is not None and rank == 0:
         print("front() ms per call:", trace_front, file=sys.stderr)
@@ -502,7 +525,10 @@ def main():
                                    f"{ds.n_viewed} viewed frames @{h}x{w}, {m} masks/view (Ins={ds.n_rows}), "
                                    f"stage-1 S1={len(scenes[0].stage1['ins'])}, 198x768 f16 text bank; inputs RESIDENT in "
                                    f"HBM (uploaded before the timed region); {n_scenes} different scenes rotate through the loop",
-                       "scenes_per_step": world, "priming_steps_in_setup": priming, "sharding": "one scene per GPU, RCCL gather of final masks",
+                       "scenes_per_step": world, "priming_steps_in_setup": priming,
+                       "sharding": "one scene per GPU and step; scenes of one rank form query classes of class_batch scenes: ONE "
+                                   "all-gather of similarity sets + ONE RCCL gather of final masks per class (none at N = 1)",
+                       "class_batch": cbatch, "similarity_exchanges_in_timed_region": n_exchanges,
                        "pipelining": "none" if args.no_pipeline else
                        f"{depth} HIP streams: the device work of the next {depth - 1} scene(s) overlaps the host half of scene i",
                        "scene_variants": [SCENE_VARIANTS[k % len(SCENE_VARIANTS)]["kind"] for k in range(n_scenes)]},
@@ -528,7 +554,8 @@ def main():
                                "frac": l2_bytes / (mc_alone * 1e-3) / 1e9 / 34500.0, **mt},
             "host_ms": host_ms, "scene_call_device_span_ms": spans,      # wall time of the host thread per step: issuing, the host half, and the part of it spent blocked on the GPU
             "kernels_ms": {k: round(vv[2], 4) for k, vv in ks.items()},   # the kernels' own durations (events on the dispatch)
-            "result": {"per_scene (stage2_instances, final_masks)": [results.get(k) for k in range(n_scenes)]},
+            "result": {"per_scene (stage2_instances, final_masks)": [results.get(k) for k in range(n_scenes)],
+                       "last_class_on_rank0": gathered_check},
             "setup_s": round(t_setup, 1),
         }
         if upload_leg is not None:

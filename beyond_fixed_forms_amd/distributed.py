@@ -63,33 +63,61 @@ def exchange_similarities(local_sims: List[List[float]], device="cpu") -> List[L
 
 
 class ClassExchange:
-    """The one exchange of a class as a callable for `refine_class(exchange_sims=...)`: a single all-gather
+    """The one exchange of a class as a callable for `ClassRefiner(exchange_sims=...)`: a single all-gather
     carries every rank's similarity set AND its bound on the final rows it will produce (known after pass 1:
     matched stage-2 rows + other stage-1 masks of the query label, R:293, 340-392), so that the later gather of
     the results (`gather_final_rows(rows, bounds=exchange.bounds)`) needs no size exchange and no host
-    synchronisation of its own."""
+    synchronisation of its own.  It is called ONCE per class (the reference picks one threshold per class,
+    R:316-324) and is the only point of a class at which the host waits for other ranks.  Over RCCL the 2 KB
+    message travels on a stream of its own (pinned staging both ways), so the wait never includes the scene
+    kernels queued on the compute streams."""
     takes_bounds = True
 
     def __init__(self, device="cpu"):
         self.device = device
         self.bounds = None                      # (max rows, max words) over all ranks after a call
+        self.calls = 0
+        self._comm = None                       # (stream, pinned send, pinned receive, device send, device receive)
+
+    def _rccl_buffers(self, ws):
+        if self._comm is None or self._comm[2].shape[0] != ws:
+            dev = torch.device(self.device)
+            self._comm = (torch.cuda.Stream(device=dev),
+                          torch.zeros(MAX_SIMS + 3, dtype=torch.float64).pin_memory(),
+                          torch.zeros((ws, MAX_SIMS + 3), dtype=torch.float64).pin_memory(),
+                          torch.zeros(MAX_SIMS + 3, dtype=torch.float64, device=dev),
+                          torch.zeros((ws, MAX_SIMS + 3), dtype=torch.float64, device=dev))
+        return self._comm
 
     def __call__(self, local_sims, bounds=(0, 1)):
         rank, ws = world()
+        self.calls += 1
         if ws == 1:
             self.bounds = (int(bounds[0]), int(bounds[1]))
             return local_sims
         uniq = sorted(set(s for sims in local_sims for s in sims))
         if len(uniq) > MAX_SIMS:
             raise ValueError(f"{len(uniq)} distinct similarities on one rank (> {MAX_SIMS})")
-        host = torch.zeros(MAX_SIMS + 3, dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            st, send_h, recv_h, send_d, recv_d = self._rccl_buffers(ws)
+            host = send_h
+        else:
+            host = torch.zeros(MAX_SIMS + 3, dtype=torch.float64)
+        host.zero_()
         host[0], host[1], host[2] = len(uniq), float(bounds[0]), float(bounds[1])
         if uniq:
             host[3:3 + len(uniq)] = torch.tensor(uniq, dtype=torch.float64)
-        buf = host if dist.get_backend() != "nccl" else host.to(self.device)
-        out = [torch.empty_like(buf) for _ in range(ws)]
-        dist.all_gather(out, buf)
-        out = [o.cpu() for o in out]
+        if dist.get_backend() == "nccl":
+            with torch.cuda.stream(st):
+                send_d.copy_(send_h, non_blocking=True)
+                dist.all_gather_into_tensor(recv_d, send_d)
+                recv_h.copy_(recv_d, non_blocking=True)
+            st.synchronize()                    # this stream only: the scene streams keep running
+            out = recv_h
+        else:
+            got = [torch.empty_like(host) for _ in range(ws)]
+            dist.all_gather(got, host)
+            out = torch.stack(got)
         self.bounds = (max(int(o[1]) for o in out), max(1, max(int(o[2]) for o in out)))
         return [o[3:3 + int(o[0])].tolist() for o in out]
 
@@ -149,115 +177,143 @@ class PaddedRows:
 
 
 _CONF_CODES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
+_META_FIXED = 4            # meta words before the scene descriptors: header rows, s_max, total rows, reserved
+_DESC = 6                  # words per scene slot
 
 
-def pack_class_results(local, scene_index, s_max, device):
-    """{scene_id: (rows int64 [R][nw] | None, conf tensor | [], final_class)} of this rank -> ONE int64 matrix
-    [s_max + sum R][nw_max + 1] for a single gather: first s_max descriptor rows (global scene index, R, nw,
-    saved-as-lists flag, confidence dtype code; unused ones hold -1), then the bit rows of all scenes, each with its
-    confidence (float64 bits) in the extra last column.  final_class needs no transport: every row carries the
-    query (R:343, 390)."""
-    nw_max = max([r.shape[1] for r, _, _ in local.values() if r is not None] + [4])     # >= 5 columns for the descriptors
-    total = sum(0 if r is None else r.shape[0] for r, _, _ in local.values())
-    out = torch.zeros((s_max + total, nw_max + 1), dtype=torch.int64, device=device)
-    desc = torch.full((s_max, 5), -1, dtype=torch.int64)
-    at = s_max
-    for k, (sid, (rows, conf, _cls)) in enumerate(local.items()):
+def packed_header_rows(s_max, r_cap, width):
+    """Leading rows of a packed class result: 4 fixed words + 6 per scene slot + one confidence per result row."""
+    return -(-(_META_FIXED + _DESC * s_max + r_cap) // width)
+
+
+def pack_class_results(final, scene_index, s_max, device, bounds=None):
+    """{scene_id: refinement.FinalResult} of this rank -> ONE int64 matrix [H + sum R][W] for a single gather.
+    The H leading rows are host-built metadata, uploaded in one copy: H, s_max, sum R; then per scene slot (global
+    scene index, R, nw, saved-as-lists flag, confidence dtype code, point count N; unused slots hold -1); then the
+    confidence (float64 bits) of every result row.  The bit rows of all scenes follow, each padded to W words.
+    final_class needs no transport: every row carries the query (R:343, 390).
+    bounds = (row bound, word bound) agreed by all ranks (ClassExchange.bounds) fixes H and W for everybody."""
+    import numpy as np
+    nw_max = max([f.rows.shape[1] for f in final.values() if f.rows is not None] + [1])
+    total = sum(0 if f.rows is None else f.rows.shape[0] for f in final.values())
+    r_cap, width = (total, nw_max) if bounds is None else (int(bounds[0]), int(bounds[1]))
+    width = max(width, 8)
+    if total > r_cap or nw_max > width or len(final) > s_max:
+        raise ValueError(f"results ({len(final)} scenes, {total} rows, {nw_max} words) exceed the agreed bounds")
+    h = packed_header_rows(s_max, r_cap, width)
+    meta = np.full(h * width, -1, dtype=np.int64)
+    meta[:_META_FIXED] = (h, s_max, total, 0)
+    at, pieces = 0, []
+    for k, (sid, f) in enumerate(final.items()):
+        rows, conf = f.rows, f.conf
         r = 0 if rows is None else rows.shape[0]
-        code = 0
-        if rows is not None and torch.is_tensor(conf):
-            code = _CONF_CODES[conf.dtype]
+        code = _CONF_CODES[conf.dtype] if (rows is not None and torch.is_tensor(conf)) else 0
+        meta[_META_FIXED + _DESC * k:_META_FIXED + _DESC * (k + 1)] = (
+            scene_index[sid], r, 0 if rows is None else rows.shape[1], 1 if rows is None else 0, code, f.n_points)
         if r:
-            out[at:at + r, :rows.shape[1]] = rows
-            out[at:at + r, nw_max] = torch.as_tensor(conf).to(torch.float64).view(torch.int64).to(device)
-        desc[k] = torch.tensor([scene_index[sid], r, 0 if rows is None else rows.shape[1], 1 if rows is None else 0, code])
+            c0 = _META_FIXED + _DESC * s_max + at
+            meta[c0:c0 + r] = torch.as_tensor(conf).detach().cpu().to(torch.float64).view(torch.int64).numpy()
+            pieces.append((at, rows))
         at += r
-    out[:s_max, :5] = desc.to(device)
+    out = torch.zeros((h + total, width), dtype=torch.int64, device=device)
+    head = torch.from_numpy(meta)
+    if torch.device(device).type == "cuda":
+        head = head.pin_memory()
+    out[:h].view(-1).copy_(head, non_blocking=True)
+    for at, rows in pieces:
+        out[h + at:h + at + rows.shape[0], :rows.shape[1]] = rows
     return out
 
 
-def unpack_class_results(mat, scene_ids, s_max, text_prompt):
-    """Inverse of pack_class_results for one rank's matrix (host or device tensor)."""
-    mat = mat.cpu()
-    nw_max = mat.shape[1] - 1
-    out, at = {}, s_max
+def unpack_class_results(mat, scene_ids, s_max, text_prompt, device="cpu"):
+    """Inverse of pack_class_results for one rank's matrix: {scene_id: FinalResult} with the bit rows on `device`."""
+    from .refinement import FinalResult
+    host = mat.cpu()
+    flat = host.reshape(-1)
+    h, s_got, total = (int(v) for v in flat[:3])
+    if s_got != s_max:
+        raise ValueError(f"packed result with {s_got} scene slots, expected {s_max}")
+    out, at = {}, 0
     dtypes = {v: k for k, v in _CONF_CODES.items()}
+    conf0 = _META_FIXED + _DESC * s_max
     for k in range(s_max):
-        idx, r, nw, is_list, code = (int(v) for v in mat[k, :5])
+        idx, r, nw, is_list, code, n_points = (int(v) for v in flat[_META_FIXED + _DESC * k:_META_FIXED + _DESC * (k + 1)])
         if idx < 0:
             continue
+        sid = scene_ids[idx]
         if is_list:
-            out[scene_ids[idx]] = (None, [], [])
+            out[sid] = FinalResult(sid, n_points, None, [], [])
             continue
-        rows = mat[at:at + r, :nw].contiguous()
-        conf = mat[at:at + r, nw_max].contiguous().view(torch.float64).to(dtypes[code])
-        out[scene_ids[idx]] = (rows, conf, [text_prompt] * r)
+        rows = mat[h + at:h + at + r, :nw].to(device).contiguous()
+        conf = flat[conf0 + at:conf0 + at + r].contiguous().view(torch.float64).to(dtypes[code])
+        out[sid] = FinalResult(sid, n_points, rows, conf, [text_prompt] * r)
         at += r
     return out
 
 
-def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[float] = None):
+class ClassBatch:
+    """One query class over this rank's scenes: pass 1 of the refinement scene by scene as the projection results
+    arrive (`add`), then `finish()`: ONE all-gather (ClassExchange: every rank's similarity set -- the threshold is a
+    percentile over the set of all scenes' similarities, refinement.py:316-324 -- and its bound on the rows it will
+    deliver), pass 2, ONE gather of equally padded result matrices to rank 0 (bit rows + confidences + a few
+    descriptor words; pack_class_results).  No object collectives, no size exchange, no per-scene host wait; the gathered
+    buffers are decoded by `results()` whenever the caller wants them (bench.py: after the timed loop).
+
+    all_ids: the scene ids of the WHOLE class in listing order, the same list on every rank; s_max: most scenes any
+    rank owns."""
+
+    def __init__(self, cfg, text_prompt, sim, device, all_ids, s_max, exchange: "ClassExchange" = None):
+        from .refinement import ClassRefiner
+        rank, ws = world()
+        self.rank, self.ws = rank, ws
+        self.device, self.text_prompt = device, text_prompt
+        self.ids, self.s_max = list(all_ids), int(s_max)
+        self.index = {sid: i for i, sid in enumerate(self.ids)}
+        self.exchange = exchange if exchange is not None else (ClassExchange(device) if ws > 1 else None)
+        self.refiner = ClassRefiner(cfg, text_prompt, sim, device, exchange_sims=self.exchange)
+        self.final = None
+        self.gathered = None
+
+    def add(self, scene_id, stage1, stage2):
+        return self.refiner.add(scene_id, stage1, stage2)
+
+    def finish(self):
+        final = self.refiner.finish() if (self.refiner.order or self.ws > 1) else {}
+        self.final = final
+        if self.ws > 1:
+            r_max, w_max = self.exchange.bounds
+            width = max(w_max, 8)
+            mat = pack_class_results(final, self.index, self.s_max, self.device, bounds=(r_max, width))
+            # every rank sends the same shape: header rows + the largest row count any rank delivers
+            self.gathered = gather_final_rows(mat, bounds=(packed_header_rows(self.s_max, r_max, width) + r_max, width))
+        return self
+
+    def results(self):
+        """rank 0: {scene_id: FinalResult} for ALL scenes of the class; other ranks: their own shard."""
+        if self.ws == 1 or self.rank != 0:
+            return self.final
+        out = {}
+        for g in self.gathered:                                 # the gathered headers are read here, not in the loop
+            out.update(unpack_class_results(g.rows(), self.ids, self.s_max, self.text_prompt, self.device))
+        return out
+
+
+def run_class(scenes, cfg, text_prompt: str, sim, device, weights: Sequence[float] = None, n_loaders: int = 2,
+              ids: Sequence[str] = None):
     """One query class over many scenes on all ranks (the multi-GPU form of running
     tools/projection_2d_to_3d.py + tools/refinement.py for that class).
 
-    scenes: list of SceneInputs-like objects (same list on every rank; only the rank's shard is touched).
-    Rank r projects and refines the scenes `shard_scenes` gives it.  Two collectives, the same two `bench.py
-    --gpus N` times: ONE all-gather (ClassExchange: every rank's similarity set -- the threshold is a percentile
-    over the set of all scenes' similarities, refinement.py:316-324 -- and its bound on the rows it will deliver)
-    and ONE gather of equally padded result matrices (bit rows + confidences + a few descriptor rows;
-    pack_class_results).  No object collectives, no size exchange; the gathered header is read after the loop.
-    Returns, on rank 0, {scene_id: (rows int64 [R][nw] or None, conf, final_class)} for ALL scenes; on the other
-    ranks the dict of their own shard."""
-    from .projection import projection_back, projection_front
-    from .refinement import prepare_stage1, refine_class
-    from .scene import prepare_scene
+    scenes: list of SceneInputs-like objects, or of zero-argument callables that load one (same list on every rank;
+    only the rank's shard is touched).  Rank r ingests (loader threads with their own streams, ingest.Ingestor),
+    projects (PIPELINE_DEPTH scenes in flight) and refines the scenes `shard_scenes` gives it; two collectives in
+    all (ClassBatch).  Returns, on rank 0, {scene_id: refinement.FinalResult} for ALL scenes; on the other ranks the
+    dict of their own shard."""
+    from .pipeline import project_stream
     rank, ws = world()
-    ids = [s.scene_id for s in scenes]
+    ids = list(ids) if ids is not None else [s.scene_id for s in scenes]
     mine = shard_scenes(ids, weights=weights)
     s_max = max(1, -(-len(scenes) // ws))                  # most scenes any rank owns
-    with_viewed = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
-    # software pipeline over PIPELINE_DEPTH HIP streams: the device work of the next scenes is issued before the host
-    # finishes scene k
-    from .pipeline import PIPELINE_DEPTH as depth, scene_streams
-    on_gpu = torch.device(device).type == "cuda"
-    streams = scene_streams(device) if on_gpu else None      # the same streams (and workspaces) for every class
-
-    def front(k):
-        sc = scenes[mine[k]]
-        ds = prepare_scene(sc, cfg, device=device, with_viewed=with_viewed)
-        st1 = prepare_stage1(sc.stage1, device)
-        if streams is None:
-            return projection_front(ds, cfg, stage1=st1), st1
-        streams[k % depth].wait_stream(torch.cuda.current_stream())   # the uploads ran on the current stream
-        with torch.cuda.stream(streams[k % depth]):
-            return projection_front(ds, cfg, stage1=st1), st1
-
-    def back(k, fr):
-        if streams is None:
-            return projection_back(fr)
-        with torch.cuda.stream(streams[k % depth]):
-            res = projection_back(fr)
-        torch.cuda.current_stream().wait_stream(streams[k % depth])   # results are used on the current stream
-        return res
-
-    trip, inflight, issued = [], [], 0
-    for k, i in enumerate(mine):
-        while issued < len(mine) and issued - k < depth:       # scenes k .. k + depth - 1 are on the device
-            inflight.append(front(issued))
-            issued += 1
-        cur, st1 = inflight.pop(0)
-        trip.append((scenes[i].scene_id, st1, back(k, cur)))
-    exchange = ClassExchange(device) if ws > 1 else None
-    final = refine_class(trip, cfg, text_prompt, sim, device, exchange_sims=exchange) if trip or ws > 1 else {}
-    local = {sid: (r.rows, r.conf, list(r.final_class)) for sid, r in final.items()}
-    if ws == 1:
-        return local
-    mat = pack_class_results(local, {sid: i for i, sid in enumerate(ids)}, s_max, device)
-    r_max, w_max = exchange.bounds
-    gathered = gather_final_rows(mat, bounds=(s_max + r_max, max(w_max, 4) + 1))
-    if rank != 0:
-        return local
-    out = {}
-    for g in gathered:                                      # the header is read here, after the loop
-        out.update(unpack_class_results(g.rows(), ids, s_max, text_prompt))
-    return out
+    batch = ClassBatch(cfg, text_prompt, sim, device, ids, s_max)
+    project_stream([scenes[i] for i in mine], cfg, device, lambda k, st1, res: batch.add(ids[mine[k]], st1, res),
+                   n_loaders=n_loaders)
+    return batch.finish().results()

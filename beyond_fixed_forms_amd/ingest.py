@@ -291,9 +291,12 @@ class Ingestor:
     (`stream.wait_event`) -- it never blocks on the upload itself -- so the host->device traffic of scene i+1 runs
     under the kernels of scene i."""
 
-    def __init__(self, cfg, device, n_loaders=4, native_threads=4, with_viewed=True):
+    def __init__(self, cfg, device, n_loaders=4, native_threads=4, with_viewed=True, with_stage1=True):
         self.cfg, self.device = cfg, torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:      # loader threads select the device by index
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.with_viewed = with_viewed
+        self.with_stage1 = with_stage1
         self.native_threads = native_threads
         self.pool = ThreadPoolExecutor(max_workers=n_loaders, thread_name_prefix="bff-loader")
         self.local = threading.local()
@@ -301,6 +304,8 @@ class Ingestor:
         _lib.load()
 
     def _work(self, scene):
+        if callable(scene):                           # a loader (e.g. io.load_scene of one scene): file reads run here too
+            scene = scene()
         tl = self.local
         if not hasattr(tl, "stream"):
             torch.cuda.set_device(self.device)
@@ -309,7 +314,7 @@ class Ingestor:
         with torch.cuda.stream(tl.stream):
             ds = prepare_scene_fast(scene, self.cfg, self.device, self.with_viewed, tl.staging, self.native_threads)
             st1 = None
-            if getattr(scene, "stage1", None) is not None:
+            if self.with_stage1 and getattr(scene, "stage1", None) is not None:
                 st1 = prepare_stage1_fast(scene.stage1, self.device, tl.staging)
                 tl.staging.fence()
             ev = torch.cuda.Event()

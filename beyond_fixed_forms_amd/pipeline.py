@@ -301,3 +301,67 @@ def collect(h):
     if hdr[HDR_K + 1] != 0:
         ws.rows_dirty = True                      # the general path reads the rows and clears them itself
     return hdr
+
+
+def pipelined(n, front, back, depth=None):
+    """The software pipeline every caller uses: `front(i)` issues the device work of item i without waiting for
+    anything, `back(i, handle)` finishes it on the host; `depth` items are in flight, i.e. while the host works on
+    the back half of item i the device already runs items i+1 .. i+depth-1.  Generator of back()'s results."""
+    depth = PIPELINE_DEPTH if depth is None else max(1, int(depth))
+    inflight, issued = [], 0
+    for i in range(n):
+        while issued < n and issued - i < depth:
+            inflight.append(front(issued))
+            issued += 1
+        yield back(i, inflight.pop(0))
+
+
+def project_stream(scenes, cfg, device, consume, n_loaders=2, with_stage1=True, depth=None, want_groups=False):
+    """Projection stage (P:365-634) of a sequence of scenes on one GPU, overlapped end to end: loader threads read
+    / ingest scenes ahead on their own streams (ingest.Ingestor: native run tables, pinned uploads, cloud laid out on
+    the device), PIPELINE_DEPTH scenes are in flight on the compute streams, the host half of scene i runs under the
+    kernels of the next ones.  `scenes`: SceneInputs-like objects or zero-argument callables that load one (called on
+    a loader thread).  `consume(k, DeviceStage1 | None, Stage2Result)` is called in order, ON THE STREAM the scene was
+    projected on (whatever it enqueues is ordered after the scene's kernels without any synchronisation); a load error
+    surfaces at that scene's turn."""
+    from .ingest import Ingestor
+    from .projection import projection_back, projection_front
+    dev = torch.device(device)
+    depth = PIPELINE_DEPTH if depth is None else depth
+    n = len(scenes)
+    if n == 0:
+        return
+    with_viewed = (not cfg.if_occurance_threshold) and bool(cfg.if_detected_ratio_threshold)
+    if dev.type != "cuda":                      # host tensors: no streams, no loaders (the kernels themselves need the GPU)
+        from .refinement import prepare_stage1
+        from .scene import prepare_scene
+        for k, sc in enumerate(scenes):
+            sc = sc() if callable(sc) else sc
+            ds = prepare_scene(sc, cfg, device=device, with_viewed=with_viewed)
+            st1 = prepare_stage1(sc.stage1, device) if (with_stage1 and getattr(sc, "stage1", None) is not None) else None
+            consume(k, st1, projection_back(projection_front(ds, cfg, stage1=st1), want_groups=want_groups))
+        return
+    streams = scene_streams(dev, depth)
+    ing = Ingestor(cfg, dev, n_loaders=n_loaders, with_viewed=with_viewed, with_stage1=with_stage1)
+    lookahead = depth + n_loaders
+    futs = {i: ing.submit(scenes[i]) for i in range(min(lookahead, n))}
+
+    def front(i):
+        ds, st1, ev = futs.pop(i).result()
+        if i + lookahead < n:
+            futs[i + lookahead] = ing.submit(scenes[i + lookahead])
+        st = streams[i % depth]
+        st.wait_event(ev)                       # the uploads ran on the loader's stream
+        with torch.cuda.stream(st):
+            return projection_front(ds, cfg, stage1=st1), st1
+
+    def back(i, h):
+        fr, st1 = h
+        with torch.cuda.stream(streams[i % depth]):
+            consume(i, st1, projection_back(fr, want_groups=want_groups))
+
+    try:
+        for _ in pipelined(n, front, back, depth):
+            pass
+    finally:
+        ing.close()

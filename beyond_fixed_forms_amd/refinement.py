@@ -159,6 +159,7 @@ class _SceneState:
     stage2_rows: Optional[torch.Tensor]
     stage2_conf: object
     other1: torch.Tensor         # bit rows (o, nw)
+    ready: object = None         # event on the stream pass 1 was issued on (None on the CPU)
 
 
 def _pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim: TextSimilarity, device) -> _SceneState:
@@ -313,6 +314,66 @@ def _pass2_scene(st: _SceneState, cfg, text_prompt, sim_thres) -> FinalResult:
     return FinalResult(st.scene_id, st.n_points, rows, conf, cls)                   # R:411-412
 
 
+class ClassRefiner:
+    """The two passes of R:135-428 for one query class as an object, so that a caller can run pass 1 scene by scene as
+    the projection results arrive (`add`, R:166-312) and the class-wide part -- ONE similarity threshold over all scenes
+    of the class (R:316-324), then pass 2 (R:330-428) -- when the class batch is complete (`finish`).
+    `exchange_sims` widens the similarity set to all ranks (the one cross-scene dependency of the path)."""
+
+    def __init__(self, cfg, text_prompt: str, sim: TextSimilarity, device="cuda", exchange_sims=None):
+        self.cfg, self.text_prompt, self.sim, self.device = cfg, text_prompt, sim, device
+        self.query_us = text_prompt.replace(" ", "_")                               # R:142
+        self.exchange_sims = exchange_sims
+        self.order = []                     # scene ids in the order given (R:154), including the skipped ones
+        self.states = []                    # pass-1 states of the scenes that have both files (R:175-178)
+        self.sim_thres = None
+
+    def add(self, scene_id, stage1, stage2):
+        """Pass 1 of one scene (device work is enqueued on the current stream)."""
+        self.order.append(scene_id)
+        if stage1 is None or stage2 is None:
+            return None
+        with _lib.launch_stream():
+            st = _pass1_scene(scene_id, stage1, stage2, self.cfg, self.text_prompt, self.query_us, self.sim, self.device)
+        if st.other1.is_cuda:               # pass 2 may run on another stream (scenes are issued round-robin on several)
+            st.ready = torch.cuda.Event()
+            st.ready.record(torch.cuda.current_stream(st.other1.device))
+        self.states.append(st)
+        return st
+
+    def bounds(self):
+        """What this rank can at most deliver: matched stage-2 rows + other stage-1 masks, widest row."""
+        rows = sum(len(st.ious) + st.other1.shape[0] for st in self.states)
+        words = max([st.other1.shape[1] for st in self.states] + [1])
+        return rows, words
+
+    def finish(self):
+        with _lib.launch_stream():
+            return self._finish()
+
+    def _finish(self):
+        all_sims = [st.sims for st in self.states]
+        ex = self.exchange_sims
+        if ex is not None and getattr(ex, "takes_bounds", False):
+            pool = ex(all_sims, bounds=self.bounds())
+        else:
+            pool = ex(all_sims) if ex is not None else all_sims
+        self.sim_thres = thres = sim_threshold(pool, self.cfg.refinment_sim_percentile)      # R:321-324
+        out = {}
+        for s, scene_id in enumerate(self.order):                                   # R:330 (index s, as the reference)
+            st = self.states[s]
+            if st.ready is not None:        # rows of pass 1 were produced on that scene's stream
+                cur = torch.cuda.current_stream(st.other1.device)
+                cur.wait_event(st.ready)
+                for t in (st.matched1, st.stage2_rows, st.other1):
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(cur)
+            res = _pass2_scene(st, self.cfg, self.text_prompt, thres)
+            res.scene_id = scene_id
+            out[scene_id] = res
+        return out
+
+
 def refine_class(scenes, cfg, text_prompt: str, sim: TextSimilarity, device="cuda",
                  exchange_sims: Optional[Callable[[List[List[float]]], List[List[float]]]] = None,
                  return_debug: bool = False):
@@ -329,27 +390,10 @@ def refine_class(scenes, cfg, text_prompt: str, sim: TextSimilarity, device="cud
 
 
 def _refine_class(scenes, cfg, text_prompt, sim, device, exchange_sims, return_debug):
-    query_us = text_prompt.replace(" ", "_")                                        # R:142
-    states = []
+    ref = ClassRefiner(cfg, text_prompt, sim, device, exchange_sims)
     for scene_id, stage1, stage2 in scenes:                                         # R:166
-        if stage1 is None or stage2 is None:
-            continue
-        states.append(_pass1_scene(scene_id, stage1, stage2, cfg, text_prompt, query_us, sim, device))
-    all_sims = [st.sims for st in states]
-    if exchange_sims is not None and getattr(exchange_sims, "takes_bounds", False):
-        # what this rank can at most deliver: matched stage-2 rows + other stage-1 masks, widest row
-        bound_rows = sum(len(st.ious) + st.other1.shape[0] for st in states)
-        bound_words = max([st.other1.shape[1] for st in states] + [1])
-        pool = exchange_sims(all_sims, bounds=(bound_rows, bound_words))
-    else:
-        pool = exchange_sims(all_sims) if exchange_sims is not None else all_sims
-    thres = sim_threshold(pool, cfg.refinment_sim_percentile)                       # R:321-324
-    out = {}
-    for s, (scene_id, _s1, _s2) in enumerate(scenes):                               # R:330 (index s, as the reference)
-        st = states[s]
-        res = _pass2_scene(st, cfg, text_prompt, thres)
-        res.scene_id = scene_id
-        out[scene_id] = res
+        ref.add(scene_id, stage1, stage2)
+    out = ref.finish()
     if return_debug:
-        return out, {"sim_thres": thres, "states": states}
+        return out, {"sim_thres": ref.sim_thres, "states": ref.states}
     return out

@@ -38,32 +38,35 @@ def _worker(rank, world, port, q):
     assert (g2 is None) == (gathered is None)
     if g2 is not None:
         assert [g.tolist() for g in g2] == [g.tolist() for g in gathered]
-    # the result transport of run_class: descriptor rows + bit rows + confidences in ONE padded gather
+    # the result transport of a class (ClassBatch): metadata rows + bit rows of all scenes in ONE padded gather
+    from beyond_fixed_forms_amd.refinement import FinalResult
     ids = [f"scene{i:04d}_00" for i in range(5)]
     gen = torch.Generator().manual_seed(rank)
     local = {}
     for i in mine:
         r = (i * 3 + 1) % 4                                   # 1, 0 (-> empty tensor form), 3, 2, ... rows
         if i == 3:
-            local[ids[i]] = (None, [], [])                    # the reference's list-valued empty form
+            local[ids[i]] = FinalResult(ids[i], 300 + i, None, [], [])      # the reference's list-valued empty form
         else:
-            local[ids[i]] = (torch.randint(-2 ** 62, 2 ** 62, (r, 5 + i), generator=gen),
-                             torch.rand(r, generator=gen).to(torch.float16 if i % 2 else torch.float32), ["q"] * r)
+            local[ids[i]] = FinalResult(ids[i], 300 + i, torch.randint(-2 ** 62, 2 ** 62, (r, 5 + i), generator=gen),
+                                        torch.rand(r, generator=gen).to(torch.float16 if i % 2 else torch.float32), ["q"] * r)
     s_max = 3
     ex2 = bd.ClassExchange()
-    ex2([[0.1]], bounds=(sum(0 if v[0] is None else v[0].shape[0] for v in local.values()),
-                         max([v[0].shape[1] for v in local.values() if v[0] is not None] + [1])))
-    mat = bd.pack_class_results(local, {sid: k for k, sid in enumerate(ids)}, s_max, "cpu")
-    g3 = bd.gather_final_rows(mat, bounds=(s_max + ex2.bounds[0], max(ex2.bounds[1], 4) + 1))
+    ex2([[0.1]], bounds=(sum(0 if v.rows is None else v.rows.shape[0] for v in local.values()),
+                         max([v.rows.shape[1] for v in local.values() if v.rows is not None] + [1])))
+    r_max, width = ex2.bounds[0], max(ex2.bounds[1], 8)
+    mat = bd.pack_class_results(local, {sid: k for k, sid in enumerate(ids)}, s_max, "cpu", bounds=(r_max, width))
+    g3 = bd.gather_final_rows(mat, bounds=(bd.packed_header_rows(s_max, r_max, width) + r_max, width))
+    plain = lambda d: {k: (v.n_points, None if v.rows is None else v.rows.tolist(),
+                           v.conf if isinstance(v.conf, list) else (str(v.conf.dtype), v.conf.tolist()), v.final_class)
+                       for k, v in d.items()}
     merged = None
     if g3 is not None:
         merged = {}
         for g in g3:
             merged.update(bd.unpack_class_results(g.rows(), ids, s_max, "q"))
-        merged = {k: (None if v[0] is None else v[0].tolist(), v[1] if isinstance(v[1], list) else (str(v[1].dtype), v[1].tolist()), v[2])
-                  for k, v in merged.items()}
-    mine_plain = {k: (None if v[0] is None else v[0].tolist(), v[1] if isinstance(v[1], list) else (str(v[1].dtype), v[1].tolist()), v[2])
-                  for k, v in local.items()}
+        merged = plain(merged)
+    mine_plain = plain(local)
     q.put((rank, mine, thr, None if gathered is None else [g.tolist() for g in gathered], mine_plain, merged))
     dist.barrier()
     dist.destroy_process_group()

@@ -341,7 +341,8 @@ def _run_class_worker(rank, world, port, q, over=None):
     out = bd.run_class(scenes, cfg, "table", TextSimilarity(bank_encoder(bank.float(), index), DEV), DEV,
                        weights=[s.points.shape[0] * len(s.mask_2d) for s in scenes])
     if rank == 0:
-        q.put({sid: (None if r is None else r.cpu(), c if isinstance(c, list) else c.cpu(), cls) for sid, (r, c, cls) in out.items()})
+        q.put({sid: (None if f.rows is None else f.rows.cpu(), f.conf if isinstance(f.conf, list) else f.conf.cpu(), list(f.final_class),
+                     f.n_points) for sid, f in out.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -376,12 +377,13 @@ def test_run_class_two_ranks_equals_single_process(api, over):
             trip.append((sc.scene_id, sc.stage1, pref.project_scene_ref(sc, cfg)))
     exp = rref.refine_class_ref(trip, cfg, "table", enc)
     assert sorted(got) == sorted(exp)
-    for sid, (rows, conf, cls) in got.items():
+    for sid, (rows, conf, cls, n_points) in got.items():
         e = exp[sid]
         if isinstance(e["ins"], list):
             assert rows is None and cls == []
             continue
         n = e["ins"].shape[1]
+        assert n_points == n
         dense = np.unpackbits(rows.numpy().view(np.uint8), axis=-1, bitorder="little")[:, :n].astype(bool)
         assert np.array_equal(dense, e["ins"].numpy()) and torch.equal(conf, e["conf"]) and cls == e["final_class"]
 
