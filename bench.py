@@ -32,6 +32,8 @@ os.environ.setdefault("OMP_NUM_THREADS", str(_NCPU))
 import argparse
 import copy
 import json
+
+import numpy as np
 import sys
 import time
 import warnings
@@ -48,7 +50,7 @@ from beyond_fixed_forms_amd.pipeline import PIPELINE_DEPTH, pipelined, scene_str
 from beyond_fixed_forms_amd.projection import projection_back, projection_front  # noqa: E402
 from beyond_fixed_forms_amd.refinement import TextSimilarity, prepare_stage1  # noqa: E402
 from beyond_fixed_forms_amd.scene import prepare_scene  # noqa: E402
-from beyond_fixed_forms_amd.synthetic import SHAPES, make_scene, make_text_bank  # noqa: E402
+from beyond_fixed_forms_amd.synthetic import SHAPES, make_scene, make_text_bank, with_sensor_depth  # noqa: E402
 from beyond_fixed_forms_amd.timing import KernelTimers  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
@@ -88,6 +90,15 @@ def cpu_baseline(scene, cfg, enc, n_sample_views=100, threads=None):
     ratio = cfg.downsample_ratio
     keep = {f["frame_id"] for f in sub.mask_2d}
     sub.color_files = [f for f in scene.color_files if int(f[:-4]) < n_sample_views * ratio]
+    if getattr(scene, "depths_raw", None) is not None and not scene.depths:
+        # the reference holds float32 (H, W) depth after cv2.imread / 1000 + cv2.resize (P:431-436); that step is done
+        # here BEFORE the clock starts (NumPy restatement of the resize, slower than cv2: timing it would flatter the GPU)
+        from beyond_fixed_forms_amd.io import resize_bilinear_f32
+        from beyond_fixed_forms_amd.scene import viewed_frame_ids
+        need = {f["frame_id"][:-4] for f in sub.mask_2d} | set(viewed_frame_ids(sub.color_files, ratio))
+        sub.depths = {f: resize_bilinear_f32(scene.depths_raw[f].astype(np.float32) / np.float32(1000), scene.width, scene.height)
+                      for f in need}
+        sub.depths_raw = None
     stages = {}
     t0 = time.perf_counter()
     with warnings.catch_warnings():
@@ -270,19 +281,27 @@ def compulsory_traffic(ds, dev):
                        labels, maskbits, segmap)
     del maskbits, labels
     line_words = (((hw + 15) // 16 + 31) // 32 + 1) // 2 * 2
+    if ds.depth_raw is not None:
+        line_words = max(line_words, (((ds.depth_raw.shape[1] * ds.depth_raw.shape[2] + 63) // 64 + 31) // 32 + 1) // 2 * 2)
     dl = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
     ml = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
     ll = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
     k = (ctypes.c_double * 9)(*[float(v) for v in ds.cam_intr.reshape(-1)])
-    _lib.call("bff_diag_sweep_lines", _lib._ptr(ds.xyz), n, ds.xyz.shape[1], _lib._ptr(ds.inv_pose), ctypes.cast(k, ctypes.c_void_p),
-              ds.n_frames, _lib._ptr(ds.depth), _lib._ptr(ds.depth_index), ds.height, ds.width, 0.08, _lib._ptr(segmap),
-              ds.word_bits, _lib._ptr(ds.frame_mask), _lib._ptr(dl), _lib._ptr(ml), line_words, _lib._ptr(ll))
+    if ds.depth_raw is not None:
+        _lib.call("bff_diag_sweep_lines_u16", _lib._ptr(ds.xyz), n, ds.xyz.shape[1], _lib._ptr(ds.inv_pose), ctypes.cast(k, ctypes.c_void_p),
+                  ds.n_frames, _lib._ptr(ds.depth_raw), ds.depth_raw.shape[1], ds.depth_raw.shape[2], _lib._ptr(ds.depth_index),
+                  ds.height, ds.width, 0.08, _lib._ptr(segmap), ds.word_bits, _lib._ptr(ds.frame_mask), _lib._ptr(dl), _lib._ptr(ml),
+                  line_words, _lib._ptr(ll))
+    else:
+        _lib.call("bff_diag_sweep_lines", _lib._ptr(ds.xyz), n, ds.xyz.shape[1], _lib._ptr(ds.inv_pose), ctypes.cast(k, ctypes.c_void_p),
+                  ds.n_frames, _lib._ptr(ds.depth), _lib._ptr(ds.depth_index), ds.height, ds.width, 0.08, _lib._ptr(segmap),
+                  ds.word_bits, _lib._ptr(ds.frame_mask), _lib._ptr(dl), _lib._ptr(ml), line_words, _lib._ptr(ll))
     count = lambda t: int(_lib.popcount_rows(t.view(torch.int64)).sum().item())
     depth_lines, mask_lines, label_lines = count(dl), count(ml), count(ll)
     tiles = (ds.n_frames + 7) // 8
     xyz_bytes, counter_bytes = 24 * n * tiles, 16 * n
     return {"bytes": 128 * (depth_lines + mask_lines + label_lines) + xyz_bytes + counter_bytes,
-            "depth_lines_128B": depth_lines, "mask_word_lines_128B": mask_lines, "mask_label_lines_128B": label_lines, "xyz_bytes (once per 8-frame tile)": xyz_bytes,
+            "depth_lines_128B": depth_lines, "depth_format": "u16 source frames" if ds.depth_raw is not None else "f32 (H, W)", "mask_word_lines_128B": mask_lines, "mask_label_lines_128B": label_lines, "xyz_bytes (once per 8-frame tile)": xyz_bytes,
             "counter_bytes": counter_bytes}
 
 
@@ -302,6 +321,10 @@ def main():
     ap.add_argument("--host-profile", action="store_true", help="cProfile of the timed loop to stderr")
     ap.add_argument("--depth", type=int, default=PIPELINE_DEPTH, help="scenes in flight on the device (one HIP stream each)")
     ap.add_argument("--scenes", type=int, default=4, help="resident scenes rotated through the timed loop")
+    ap.add_argument("--depth-format", choices=["u16", "f32"], default="u16",
+                    help="u16 (default): depth resident as the PNGs store it (uint16 mm at half the working resolution, "
+                         "ScanNet's sensor ratio), /1000 + bilinear resize evaluated per point inside the sweep (P:431-436); "
+                         "f32: float32 (H, W) images as after cv2.resize")
     ap.add_argument("--class-batch", type=int, default=8,
                     help="scenes per GPU that form one query class: one similarity exchange + one gather per batch")
     ap.add_argument("--include-upload", action="store_true",
@@ -342,6 +365,8 @@ def main():
         var.pop("kind")
         sc = make_scene(args.shape, seed=rank * n_scenes + k, device=dev, query=QUERY, **var)
         cfg = Config.with_defaults(width_2d=sc.width, height_2d=sc.height)
+        if args.depth_format == "u16":
+            sc = with_sensor_depth(sc)
         scenes.append(sc)
         dss.append(prepare_scene(sc, cfg, device=dev))
         stage1s.append(prepare_stage1(sc.stage1, dev))          # class-independent: uploaded with the scene
@@ -506,7 +531,7 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             with open(tfile) as f:
-                traffic = json.load(f).get(f"project_views_{args.shape}")
+                traffic = json.load(f).get(f"project_views_{args.shape}" + ("_u16" if ds.depth_raw is not None else ""))
         mt = merge_traffic(ds, cfg, dev)
         comp = compulsory_traffic(ds, dev)
         t_alone = sq["project_views"][2] * 1e-3
@@ -524,7 +549,10 @@ def main():
             "config": {"workload": f"{args.shape}: 1 scene/GPU per step, {n} pts x {len(scenes[0].mask_2d)} mask views + "
                                    f"{ds.n_viewed} viewed frames @{h}x{w}, {m} masks/view (Ins={ds.n_rows}), "
                                    f"stage-1 S1={len(scenes[0].stage1['ins'])}, 198x768 f16 text bank; inputs RESIDENT in "
-                                   f"HBM (uploaded before the timed region); {n_scenes} different scenes rotate through the loop",
+                                   f"HBM (uploaded before the timed region); depth " +
+                                   (f"as stored (uint16 mm, {ds.depth_raw.shape[1]}x{ds.depth_raw.shape[2]}), /1000 + bilinear resize "
+                                    f"per point inside the sweep" if ds.depth_raw is not None else "float32 (H, W)") +
+                                   f"; {n_scenes} different scenes rotate through the loop",
                        "scenes_per_step": world, "priming_steps_in_setup": priming,
                        "sharding": "one scene per GPU and step; scenes of one rank form query classes of class_batch scenes: ONE "
                                    "all-gather of similarity sets + ONE RCCL gather of final masks per class (none at N = 1)",

@@ -24,6 +24,7 @@ SIGNATURES = {
     "bff_rle_to_maskbits": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P],
     "bff_rle_to_labels": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P],
     "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P],
+    "bff_project_views_u16": [_P, _L, _L, _P, _P, _I, _P, _I, _I, _P, _I, _I, _D, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P],
     "bff_point_tile_bounds": [_P, _L, _L, _P, _P],
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
@@ -61,6 +62,7 @@ SIGNATURES = {
     "bff_scene_project": [_P, _P, _P, _P],
     "bff_diag_gather": [_P, _L, _L, _P, _P],
     "bff_diag_sweep_lines": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _I, _P, _P, _P, _L, _P, _P],
+    "bff_diag_sweep_lines_u16": [_P, _L, _L, _P, _P, _I, _P, _I, _I, _P, _I, _I, _D, _P, _I, _P, _P, _P, _L, _P, _P],
     "bff_scatter_bits": [_P, _I, _L, _P, _L, _L, _P, _P, _P],
     "bff_cross_popcount_dev": [_P, _I, _P, _I, _L, _P, _P, _I, _I, _P],
     "bff_cloud_layout": [_P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -206,11 +208,18 @@ def rle_to_labels(run_start, run_end, mask_run_offs, view_mask_offs, n_views, n_
 def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, height, width, depth_thresh,
                   maskbits, word_bits, frame_mask, frame_rowbase, frame_nmask, frame_flags,
                   rows, masked_count, viewed_count, segmap=None, chunk_mask=None, tile_bounds=None, labels=None):
+    """depth: float32 [n_depth][H*W] metres, or int16 [n_depth][hs][ws] (the uint16 millimetres of the PNGs): then
+    /1000 + the bilinear resize to (height, width) are evaluated per point inside the sweep (bff_project_views_u16)."""
     k = (c_double * 9)(*[float(v) for v in cam_intr.reshape(-1)])
     n_frames = inv_pose.shape[0]
     nw = (n_points + 63) // 64
-    call("bff_project_views", _ptr(xyz_soa, f64), n_points, xyz_soa.shape[1], _ptr(inv_pose, f64),
-         ctypes.cast(k, c_void_p), n_frames, _ptr(depth, f32), _ptr(depth_index, i32), height, width,
+    if depth.dtype == torch.int16:
+        head = ("bff_project_views_u16", _ptr(xyz_soa, f64), n_points, xyz_soa.shape[1], _ptr(inv_pose, f64),
+                ctypes.cast(k, c_void_p), n_frames, _ptr(depth, torch.int16), depth.shape[1], depth.shape[2])
+    else:
+        head = ("bff_project_views", _ptr(xyz_soa, f64), n_points, xyz_soa.shape[1], _ptr(inv_pose, f64),
+                ctypes.cast(k, c_void_p), n_frames, _ptr(depth, f32))
+    call(*head, _ptr(depth_index, i32), height, width,
          float(depth_thresh), _ptr(maskbits), _ptr(labels, u8), _ptr(segmap, i32), word_bits, _ptr(frame_mask, i32), _ptr(frame_rowbase, i32),
          _ptr(frame_nmask, i32), _ptr(frame_flags, i32), _ptr(rows, i64),
          0 if rows is None else rows.shape[0], nw, _ptr(chunk_mask, i64), _ptr(masked_count, i32),

@@ -25,13 +25,55 @@ constexpr int kPtsPerBlock = kWordsPerBlock * kWave;       // 1024
 
 struct Intrinsics { double k[9]; };
 
+// Depth kept as the PNGs store it (P:431-436): uint16 millimetres at the sensor's resolution.  The sweep then evaluates
+// `astype(f32) / 1000` and the two 2-tap passes of the bilinear resize to (H, W) PER POINT, at the pixel the point
+// projects to, with exactly the float32 operations of depth_resize_kernel (filter.hip) / io.resize_bilinear_f32 -- the
+// (H, W) float image (8x the bytes of the source) is never built.  hs == H and ws == W: the resize is the identity.
+struct RawDepth {
+    int hs, ws;                 // source size
+    int same;                   // source size == (H, W)
+    float scale;                // 1000
+    double sx, sy;              // 1 / (W / ws), 1 / (H / hs) in float64, as io._axis_taps computes them
+};
+
+// io._axis_taps for one destination index: f = (float)((d + 0.5) * scale - 0.5) (float64 products and differences, each
+// rounded once; no contraction), i0 = floor(f), a = f - i0 in float32; x axis: border columns are copied (a = 0), y axis:
+// the fraction is kept and the two row indices are clamped.
+template <bool kX>
+__device__ __forceinline__ void axis_tap(int d, double scale, int n_src, int &i0, int &i1, float &a)
+{
+    const float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+    const float fl = floorf(f);
+    int s = (int)fl;
+    a = __fsub_rn(f, fl);
+    if (kX) {
+        if (s < 0) { s = 0; a = 0.0f; }
+        else if (s >= n_src - 1) { s = n_src - 1; a = 0.0f; }
+        i0 = s;
+        i1 = min(s + 1, n_src - 1);
+    } else {
+        i1 = min(max(s + 1, 0), n_src - 1);
+        i0 = min(max(s, 0), n_src - 1);
+    }
+}
+
+// the resized depth value at one pixel from its four source texels (same operation order as depth_resize_kernel)
+__device__ __forceinline__ float bilinear_depth(uint16_t t00, uint16_t t01, uint16_t t10, uint16_t t11, float a, float b,
+                                                float scale)
+{
+    const float one_a = __fsub_rn(1.0f, a), one_b = __fsub_rn(1.0f, b);
+    const float r0 = __fadd_rn(__fmul_rn(__fdiv_rn((float)t00, scale), one_a), __fmul_rn(__fdiv_rn((float)t01, scale), a));
+    const float r1 = __fadd_rn(__fmul_rn(__fdiv_rn((float)t10, scale), one_a), __fmul_rn(__fdiv_rn((float)t11, scale), a));
+    return __fadd_rn(__fmul_rn(r0, one_b), __fmul_rn(r1, b));
+}
+
 __device__ __forceinline__ void lds_phase_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <typename WordT, bool kLabels>
+template <typename WordT, bool kLabels, bool kRaw>
 __global__ __launch_bounds__(kBlock) void project_views_kernel(
     const double *__restrict__ xyz, int64_t n_points, int64_t n_pad,
     const double *__restrict__ inv_pose, Intrinsics K, int n_frames, int frames_per_block,
-    const float *__restrict__ depth, const int32_t *__restrict__ depth_index, int H, int W, double thresh,
+    const void *__restrict__ depth, RawDepth raw, const int32_t *__restrict__ depth_index, int H, int W, double thresh,
     const WordT *__restrict__ maskbits, const uint8_t *__restrict__ labels, int64_t label_stride,
     const uint32_t *__restrict__ segmap, int64_t seg_words,
     const int32_t *__restrict__ frame_mask,
@@ -116,7 +158,9 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
     for (int f = f0; f < f1; ++f) {
         if ((culled >> (8 * (f - f0))) & 1) continue;      // wave-uniform
         const double *P = inv_pose + 16 * (int64_t)f;
-        const float *dimg = depth + (int64_t)depth_index[f] * hw;
+        const float *dimg = kRaw ? nullptr : reinterpret_cast<const float *>(depth) + (int64_t)depth_index[f] * hw;
+        const uint16_t *rimg = kRaw ? reinterpret_cast<const uint16_t *>(depth) + (int64_t)depth_index[f] * raw.hs * raw.ws
+                                    : nullptr;
         const int mi = maskbits ? frame_mask[f] : -1;
         const bool has_masks = mi >= 0;
         const WordT *mimg = has_masks ? maskbits + (int64_t)mi * hw : nullptr;
@@ -128,6 +172,7 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
         // memory latency x concurrency, not by issue): (1) geometry of the 4 points, (2) depth + segment-bitmap
         // gathers of every in-bounds point, (3) mask-word gathers of every visible point in a masked segment.
         int pix[kPPT];
+        int pu[kPPT];                                       // kRaw: the pixel's column (its row is (pix - pu) / W)
         double cz[kPPT];
 #pragma unroll
         for (int j = 0; j < kPPT; ++j) {
@@ -141,16 +186,37 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
             const double v = rint(p1 / cz[j]);
             const bool inb = valid[j] && (u >= 0.0) && (u < dW) && (v >= 0.0) && (v < dH);   // NaN fails
             pix[j] = inb ? (int)v * W + (int)u : -1;       // H*W < 2^31 (checked by the entry point)
+            pu[j] = inb ? (int)u | ((int)v << 16) : 0;     // kRaw: H, W < 2^15 (checked by the entry point)
         }
         float dval[kPPT];
+        uint16_t t00[kPPT], t01[kPPT], t10[kPPT], t11[kPPT];
+        float ta[kPPT], tb[kPPT];
         uint32_t sbits[kPPT], fbits[kPPT];                 // fbits (kLabels): segments in word form
 #pragma unroll
         for (int j = 0; j < kPPT; ++j) {
             dval[j] = 0.0f;
             sbits[j] = 0xffffffffu;
             fbits[j] = 0xffffffffu;
+            if (kRaw) {
+                t00[j] = t01[j] = t10[j] = t11[j] = 0;
+                ta[j] = tb[j] = 0.0f;
+            }
             if (pix[j] >= 0) {
-                dval[j] = dimg[pix[j]];
+                if (kRaw) {
+                    // the four source texels of the pixel (two of them when the sizes agree): all in flight together
+                    const int ux = pu[j] & 0xffff, vy = pu[j] >> 16;
+                    if (raw.same) {
+                        t00[j] = rimg[pix[j]];
+                    } else {
+                        int x0, x1, y0, y1;
+                        axis_tap<true>(ux, raw.sx, raw.ws, x0, x1, ta[j]);
+                        axis_tap<false>(vy, raw.sy, raw.hs, y0, y1, tb[j]);
+                        const uint16_t *r0 = rimg + (int64_t)y0 * raw.ws, *r1 = rimg + (int64_t)y1 * raw.ws;
+                        t00[j] = r0[x0]; t01[j] = r0[x1]; t10[j] = r1[x0]; t11[j] = r1[x1];
+                    }
+                } else {
+                    dval[j] = dimg[pix[j]];
+                }
                 // segments without any mask pixel were never written by the decoder: consult its bitmap
                 if (kLabels) {
                     if (smap) {
@@ -162,6 +228,13 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
                     sbits[j] = smap[pix[j] >> 12];
                 }
             }
+        }
+        if (kRaw) {
+#pragma unroll
+            for (int j = 0; j < kPPT; ++j)
+                if (pix[j] >= 0)
+                    dval[j] = raw.same ? __fdiv_rn((float)t00[j], raw.scale)
+                                       : bilinear_depth(t00[j], t01[j], t10[j], t11[j], ta[j], tb[j], raw.scale);
         }
         bool vis[kPPT];
         WordT wv[kPPT];
@@ -265,7 +338,8 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
 template <typename WordT>
 __global__ void sweep_lines_kernel(const double *__restrict__ xyz, int64_t n_points, int64_t n_pad,
                                    const double *__restrict__ inv_pose, Intrinsics K, int n_frames,
-                                   const float *__restrict__ depth, const int32_t *__restrict__ depth_index, int H, int W,
+                                   const void *__restrict__ depth, RawDepth raw, bool is_raw,
+                                   const int32_t *__restrict__ depth_index, int H, int W,
                                    double thresh, const uint32_t *__restrict__ segmap, int64_t seg_words,
                                    const int32_t *__restrict__ frame_mask, uint32_t *__restrict__ depth_lines,
                                    uint32_t *__restrict__ mask_lines, int64_t line_words, uint32_t *__restrict__ label_lines)
@@ -283,9 +357,29 @@ __global__ void sweep_lines_kernel(const double *__restrict__ xyz, int64_t n_poi
     const double u = rint(p0 / cz), v = rint(p1 / cz);
     if (!((u >= 0.0) && (u < (double)W) && (v >= 0.0) && (v < (double)H))) return;
     const int pix = (int)v * W + (int)u;
-    const int dl = pix >> 5;                                            // 32 floats per 128-B line
-    atomicOr(depth_lines + (int64_t)f * line_words + (dl >> 5), 1u << (dl & 31));
-    const float d = depth[(int64_t)depth_index[f] * H * W + pix];
+    float d;
+    if (is_raw) {                                                       // uint16 source texels: 64 per 128-B line
+        const uint16_t *img = reinterpret_cast<const uint16_t *>(depth) + (int64_t)depth_index[f] * raw.hs * raw.ws;
+        auto mark = [&](int y, int x) {
+            const int l = (y * raw.ws + x) >> 6;
+            atomicOr(depth_lines + (int64_t)f * line_words + (l >> 5), 1u << (l & 31));
+            return img[(int64_t)y * raw.ws + x];
+        };
+        if (raw.same) {
+            d = __fdiv_rn((float)mark((int)v, (int)u), raw.scale);
+        } else {
+            int x0, x1, y0, y1;
+            float a, b;
+            axis_tap<true>((int)u, raw.sx, raw.ws, x0, x1, a);
+            axis_tap<false>((int)v, raw.sy, raw.hs, y0, y1, b);
+            const uint16_t t00 = mark(y0, x0), t01 = mark(y0, x1), t10 = mark(y1, x0), t11 = mark(y1, x1);
+            d = bilinear_depth(t00, t01, t10, t11, a, b, raw.scale);
+        }
+    } else {
+        const int dl = pix >> 5;                                        // 32 floats per 128-B line
+        atomicOr(depth_lines + (int64_t)f * line_words + (dl >> 5), 1u << (dl & 31));
+        d = reinterpret_cast<const float *>(depth)[(int64_t)depth_index[f] * H * W + pix];
+    }
     const int mi = frame_mask ? frame_mask[f] : -1;
     if (mi < 0 || d == 0.0f || !(fabs(cz - (double)d) < thresh)) return;
     if (label_lines) {
@@ -634,16 +728,27 @@ static int rle_decode(const int32_t *run_start, const int32_t *run_end, const in
     return launched("bff_rle_to_maskbits");
 }
 
-extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
-                                 const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
-                                 const float *depth, const int32_t *depth_index, int32_t height, int32_t width,
-                                 double depth_thresh,
-                                 const void *maskbits, const uint8_t *labels, const uint32_t *segmap, int32_t word_bits,
-                                 const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
-                                 const int32_t *frame_flags,
-                                 uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
-                                 int32_t *masked_count, int32_t *viewed_count, const double *tile_bounds,
-                                 void *stream)
+static RawDepth raw_depth_params(int32_t depth_h, int32_t depth_w, int32_t height, int32_t width)
+{
+    RawDepth r;
+    r.hs = depth_h; r.ws = depth_w;
+    r.same = depth_h == height && depth_w == width;
+    r.scale = 1000.0f;                                                  // depth_scale, hard-coded at P:346
+    r.sx = 1.0 / ((double)width / (double)depth_w);                     // io._axis_taps: 1 / (n_dst / n_src)
+    r.sy = 1.0 / ((double)height / (double)depth_h);
+    return r;
+}
+
+static int project_views_launch(const double *xyz, int64_t n_points, int64_t n_pad,
+                                const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
+                                const void *depth, const RawDepth *raw, const int32_t *depth_index, int32_t height, int32_t width,
+                                double depth_thresh,
+                                const void *maskbits, const uint8_t *labels, const uint32_t *segmap, int32_t word_bits,
+                                const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
+                                const int32_t *frame_flags,
+                                uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
+                                int32_t *masked_count, int32_t *viewed_count, const double *tile_bounds,
+                                void *stream)
 {
     BFF_REQUIRE(n_points >= 0 && n_pad >= n_points && n_frames >= 0, "bff_project_views: bad sizes");
     BFF_REQUIRE(height > 0 && width > 0, "bff_project_views: bad image size");
@@ -651,6 +756,11 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
     if (n_points == 0 || n_frames == 0) return BFF_OK;
     BFF_REQUIRE(xyz && inv_pose && cam_intr_host && depth && depth_index && frame_flags, "bff_project_views: null pointer");
     BFF_REQUIRE(nw == ceil_div(n_points, 64), "bff_project_views: nw must be ceil(n_points/64)");
+    if (raw) {
+        BFF_REQUIRE(raw->hs > 0 && raw->ws > 0, "bff_project_views_u16: bad depth size");
+        BFF_LIMIT(height < (1 << 15) && width < (1 << 16) && (int64_t)raw->hs * raw->ws < (1ll << 31),
+                  "bff_project_views_u16: image too large");
+    }
     if (maskbits) {
         BFF_REQUIRE(word_bits == 32 || word_bits == 64, "bff_project_views: word_bits must be 32 or 64");
         BFF_REQUIRE(frame_mask && frame_rowbase && frame_nmask && rows && n_rows >= 0, "bff_project_views: mask frames need row outputs");
@@ -667,15 +777,54 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
     BFF_REQUIRE(!labels || (maskbits && segmap), "bff_project_views: a label plane comes with its word plane and segment bitmap");
     const hipEvent_t ev0 = g_sweep_start, ev1 = g_sweep_stop;   // attached to the dispatch itself when set
     g_sweep_start = g_sweep_stop = nullptr;
-#define BFF_SWEEP(WORD, LAB)                                                                                            \
-    hipExtLaunchKernelGGL((project_views_kernel<WORD, LAB>), grid, dim3(kBlock), 0, as_stream(stream), ev0, ev1, 0, xyz,  \
-        n_points, n_pad, inv_pose, K, n_frames, fpb, depth, depth_index, height, width, depth_thresh,                   \
+    const RawDepth rd = raw ? *raw : RawDepth{};
+#define BFF_SWEEP(WORD, LAB, RAW)                                                                                        \
+    hipExtLaunchKernelGGL((project_views_kernel<WORD, LAB, RAW>), grid, dim3(kBlock), 0, as_stream(stream), ev0, ev1, 0,  \
+        xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, rd, depth_index, height, width, depth_thresh,           \
         (const WORD *)maskbits, labels, label_stride, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask,        \
         frame_flags, rows, nw, chunk_mask, mw, masked_count, viewed_count, tile_bounds)
-    if (!maskbits || word_bits == 32) { if (labels) BFF_SWEEP(uint32_t, true); else BFF_SWEEP(uint32_t, false); }
-    else { if (labels) BFF_SWEEP(uint64_t, true); else BFF_SWEEP(uint64_t, false); }
+#define BFF_SWEEP_LR(WORD)                                                                                               \
+    do { if (labels) { if (raw) BFF_SWEEP(WORD, true, true); else BFF_SWEEP(WORD, true, false); }                        \
+         else { if (raw) BFF_SWEEP(WORD, false, true); else BFF_SWEEP(WORD, false, false); } } while (0)
+    if (!maskbits || word_bits == 32) BFF_SWEEP_LR(uint32_t); else BFF_SWEEP_LR(uint64_t);
+#undef BFF_SWEEP_LR
 #undef BFF_SWEEP
     return launched("bff_project_views");
+}
+
+extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
+                                 const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
+                                 const float *depth, const int32_t *depth_index, int32_t height, int32_t width,
+                                 double depth_thresh,
+                                 const void *maskbits, const uint8_t *labels, const uint32_t *segmap, int32_t word_bits,
+                                 const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
+                                 const int32_t *frame_flags,
+                                 uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
+                                 int32_t *masked_count, int32_t *viewed_count, const double *tile_bounds,
+                                 void *stream)
+{
+    return project_views_launch(xyz, n_points, n_pad, inv_pose, cam_intr_host, n_frames, depth, nullptr, depth_index, height,
+                                width, depth_thresh, maskbits, labels, segmap, word_bits, frame_mask, frame_rowbase,
+                                frame_nmask, frame_flags, rows, n_rows, nw, chunk_mask, masked_count, viewed_count,
+                                tile_bounds, stream);
+}
+
+extern "C" int bff_project_views_u16(const double *xyz, int64_t n_points, int64_t n_pad,
+                                     const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
+                                     const uint16_t *depth_raw, int32_t depth_h, int32_t depth_w,
+                                     const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
+                                     const void *maskbits, const uint8_t *labels, const uint32_t *segmap, int32_t word_bits,
+                                     const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
+                                     const int32_t *frame_flags,
+                                     uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
+                                     int32_t *masked_count, int32_t *viewed_count, const double *tile_bounds,
+                                     void *stream)
+{
+    const RawDepth raw = raw_depth_params(depth_h, depth_w, height, width);
+    return project_views_launch(xyz, n_points, n_pad, inv_pose, cam_intr_host, n_frames, depth_raw, &raw, depth_index, height,
+                                width, depth_thresh, maskbits, labels, segmap, word_bits, frame_mask, frame_rowbase,
+                                frame_nmask, frame_flags, rows, n_rows, nw, chunk_mask, masked_count, viewed_count,
+                                tile_bounds, stream);
 }
 
 extern "C" int bff_point_tile_bounds(const double *xyz, int64_t n_points, int64_t n_pad, double *bounds, void *stream)
@@ -693,12 +842,12 @@ extern "C" int bff_point_tile_size(void) { return kPPT * kWave; }
 
 // Marks the 128-byte lines one sweep touches (see sweep_lines_kernel).  depth_lines / mask_lines: uint32
 // [n_frames][line_words] bitmaps, zeroed by the caller, line_words >= ceil(ceil(H*W / 16) / 32).
-extern "C" int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
-                                    const double *cam_intr_host, int32_t n_frames, const float *depth,
-                                    const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
-                                    const uint32_t *segmap, int32_t word_bits, const int32_t *frame_mask,
-                                    uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words,
-                                    uint32_t *label_lines, void *stream)
+static int diag_sweep_lines(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
+                            const double *cam_intr_host, int32_t n_frames, const void *depth, const RawDepth *raw,
+                            const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
+                            const uint32_t *segmap, int32_t word_bits, const int32_t *frame_mask,
+                            uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words,
+                            uint32_t *label_lines, void *stream)
 {
     BFF_REQUIRE(xyz && inv_pose && cam_intr_host && depth && depth_index && depth_lines && mask_lines && n_points > 0 &&
                 n_frames > 0 && (word_bits == 32 || word_bits == 64), "bff_diag_sweep_lines: bad arguments");
@@ -708,13 +857,38 @@ extern "C" int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t
     for (int i = 0; i < 9; ++i) K.k[i] = cam_intr_host[i];
     const int64_t seg_words = ceil_div(ceil_div((int64_t)height * width, 128), 32);
     dim3 grid((unsigned)ceil_div(n_points, 256), (unsigned)n_frames);
+    const RawDepth rd = raw ? *raw : RawDepth{};
     if (word_bits == 32)
-        sweep_lines_kernel<uint32_t><<<grid, 256, 0, as_stream(stream)>>>(xyz, n_points, n_pad, inv_pose, K, n_frames, depth,
-            depth_index, height, width, depth_thresh, segmap, seg_words, frame_mask, depth_lines, mask_lines, line_words,
-            label_lines);
+        sweep_lines_kernel<uint32_t><<<grid, 256, 0, as_stream(stream)>>>(xyz, n_points, n_pad, inv_pose, K, n_frames, depth, rd,
+            raw != nullptr, depth_index, height, width, depth_thresh, segmap, seg_words, frame_mask, depth_lines, mask_lines,
+            line_words, label_lines);
     else
-        sweep_lines_kernel<uint64_t><<<grid, 256, 0, as_stream(stream)>>>(xyz, n_points, n_pad, inv_pose, K, n_frames, depth,
-            depth_index, height, width, depth_thresh, segmap, seg_words, frame_mask, depth_lines, mask_lines, line_words,
-            label_lines);
+        sweep_lines_kernel<uint64_t><<<grid, 256, 0, as_stream(stream)>>>(xyz, n_points, n_pad, inv_pose, K, n_frames, depth, rd,
+            raw != nullptr, depth_index, height, width, depth_thresh, segmap, seg_words, frame_mask, depth_lines, mask_lines,
+            line_words, label_lines);
     return launched("bff_diag_sweep_lines");
+}
+
+extern "C" int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
+                                    const double *cam_intr_host, int32_t n_frames, const float *depth,
+                                    const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
+                                    const uint32_t *segmap, int32_t word_bits, const int32_t *frame_mask,
+                                    uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words,
+                                    uint32_t *label_lines, void *stream)
+{
+    return diag_sweep_lines(xyz, n_points, n_pad, inv_pose, cam_intr_host, n_frames, depth, nullptr, depth_index, height, width,
+                            depth_thresh, segmap, word_bits, frame_mask, depth_lines, mask_lines, line_words, label_lines, stream);
+}
+
+extern "C" int bff_diag_sweep_lines_u16(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
+                                        const double *cam_intr_host, int32_t n_frames, const uint16_t *depth_raw,
+                                        int32_t depth_h, int32_t depth_w,
+                                        const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
+                                        const uint32_t *segmap, int32_t word_bits, const int32_t *frame_mask,
+                                        uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words,
+                                        uint32_t *label_lines, void *stream)
+{
+    const RawDepth raw = raw_depth_params(depth_h, depth_w, height, width);
+    return diag_sweep_lines(xyz, n_points, n_pad, inv_pose, cam_intr_host, n_frames, depth_raw, &raw, depth_index, height, width,
+                            depth_thresh, segmap, word_bits, frame_mask, depth_lines, mask_lines, line_words, label_lines, stream);
 }

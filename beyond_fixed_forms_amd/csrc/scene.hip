@@ -69,10 +69,17 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
                 reinterpret_cast<char *>(ws->masked) + ws->zero_bytes, "bff_scene_project: zero block too small");
     BFF_ZERO(ws->masked, ws->zero_bytes);
     BFF_ZERO(hdr, sizeof(int32_t) * BFF_HDR_SIZES);
-    BFF_TRY(bff_project_views(sc->xyz, n, sc->n_pad, sc->inv_pose, sc->cam_intr, sc->n_frames, sc->depth, sc->depth_index,
-                              sc->height, sc->width, pr->depth_thresh, ws->maskbits, ws->labels, ws->segmap, sc->word_bits,
-                              sc->frame_mask, sc->frame_rowbase, sc->frame_nmask, sc->frame_flags, ws->rows, n_rows, nw,
-                              ws->chunk_mask, ws->masked, ratio ? ws->viewed : nullptr, sc->tile_bounds, stream));
+    if (sc->depth_raw)          // depth as the PNGs store it: /1000 + bilinear resize per point inside the sweep
+        BFF_TRY(bff_project_views_u16(sc->xyz, n, sc->n_pad, sc->inv_pose, sc->cam_intr, sc->n_frames, sc->depth_raw,
+                                      sc->depth_h, sc->depth_w, sc->depth_index, sc->height, sc->width, pr->depth_thresh,
+                                      ws->maskbits, ws->labels, ws->segmap, sc->word_bits, sc->frame_mask, sc->frame_rowbase,
+                                      sc->frame_nmask, sc->frame_flags, ws->rows, n_rows, nw, ws->chunk_mask, ws->masked,
+                                      ratio ? ws->viewed : nullptr, sc->tile_bounds, stream));
+    else
+        BFF_TRY(bff_project_views(sc->xyz, n, sc->n_pad, sc->inv_pose, sc->cam_intr, sc->n_frames, sc->depth, sc->depth_index,
+                                  sc->height, sc->width, pr->depth_thresh, ws->maskbits, ws->labels, ws->segmap, sc->word_bits,
+                                  sc->frame_mask, sc->frame_rowbase, sc->frame_nmask, sc->frame_flags, ws->rows, n_rows, nw,
+                                  ws->chunk_mask, ws->masked, ratio ? ws->viewed : nullptr, sc->tile_bounds, stream));
     // a14 / a15: point filter, threshold stays on the device (header words 2, 3 = n_unique, thr)
     if (pr->filter_mode != 0) {
         if (pr->filter_sort) {          // the general formulation: sort all n values (scenes with > 2^18 distinct ones)

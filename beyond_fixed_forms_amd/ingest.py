@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .scene import DeviceScene, prepare_scene, viewed_frame_ids
+from .scene import DeviceScene, keep_raw_depth, prepare_scene, viewed_frame_ids
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libbff_host.so")
@@ -177,6 +177,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
         inv = np.zeros((0, 16))
 
     # ---- depth: frames packed into pinned staging by native threads, ONE asynchronous copy
+    raw_keep = None
     raw_depth = getattr(scene, "depths_raw", None)
     src = raw_depth if raw_depth is not None else scene.depths
     frames = [src[f] for f in depth_ids]
@@ -195,10 +196,13 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
             from .io import bilinear_taps
             hs, ws_ = f0.shape
             raw_dev = flat.view(torch.int16).view(len(frames), hs, ws_).to(dev, non_blocking=True)
-            taps = None
-            if (hs, ws_) != (h, w):
-                taps = _taps_cache(hs, ws_, h, w, dev)
-            depth_dev = _lib.depth_from_u16(raw_dev, h, w, taps)
+            if keep_raw_depth():                     # resident as stored: the sweep resizes per point
+                depth_dev, raw_keep = None, raw_dev
+            else:
+                taps = None
+                if (hs, ws_) != (h, w):
+                    taps = _taps_cache(hs, ws_, h, w, dev)
+                depth_dev = _lib.depth_from_u16(raw_dev, h, w, taps)
         else:
             depth_dev = flat.view(torch.float32).view(len(frames), h * w).to(dev, non_blocking=True)
     else:
@@ -257,7 +261,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
         frame_flags=f_flags_d, n_frames=nf, n_mask_frames=n_mask_frames, n_viewed=len(viewed), word_bits=word_bits,
         n_rows=row, run_start=run_start, run_end=run_end, mask_run_offs=run_offs, view_mask_offs=vmo_d, conf=conf_d,
         labels=labels, label_id=label_d, n_label_ids=max(1, len(ids)), stage1=getattr(scene, "stage1", None),
-        unsort=unsort[:n] if sort else None, perm=perm if sort else None)
+        unsort=unsort[:n] if sort else None, perm=perm if sort else None, depth_raw=raw_keep)
 
 
 _taps = {}

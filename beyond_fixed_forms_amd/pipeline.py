@@ -25,7 +25,7 @@ HDR_SIZES, HDR_FIRST, HDR_BEFORE, HDR_AFTER, HDR_CONF, HDR_CROSS = (16 + k * GRO
 class SceneStruct(ctypes.Structure):
     _fields_ = [("n_points", c_int64), ("n_pad", c_int64), ("nw", c_int64),
                 ("xyz", c_void_p), ("tile_bounds", c_void_p), ("inv_pose", c_void_p), ("cam_intr", c_double * 9),
-                ("depth", c_void_p),
+                ("depth", c_void_p), ("depth_raw", c_void_p),
                 ("depth_index", c_void_p), ("frame_mask", c_void_p), ("frame_rowbase", c_void_p),
                 ("frame_nmask", c_void_p), ("frame_flags", c_void_p),
                 ("run_start", c_void_p), ("run_end", c_void_p), ("mask_run_offs", c_void_p), ("view_mask_offs", c_void_p),
@@ -33,7 +33,7 @@ class SceneStruct(ctypes.Structure):
                 ("s1_run_start", c_void_p), ("s1_run_end", c_void_p), ("s1_row_run_offs", c_void_p),
                 ("height", c_int32), ("width", c_int32), ("n_frames", c_int32), ("n_mviews", c_int32),
                 ("word_bits", c_int32), ("n_rows", c_int32), ("conf_f16", c_int32), ("n_label_ids", c_int32),
-                ("s1_rows", c_int32), ("pad_", c_int32)]
+                ("s1_rows", c_int32), ("depth_h", c_int32), ("depth_w", c_int32), ("pad_", c_int32)]
 
 
 class ParamsStruct(ctypes.Structure):
@@ -102,7 +102,11 @@ def scene_struct(ds, stage1=None, n_frames=None):
     s.n_points, s.n_pad, s.nw = ds.n_points, ds.xyz.shape[1], ds.nw
     s.xyz, s.tile_bounds, s.inv_pose = _p(ds.xyz), _p(ds.tile_bounds), _p(ds.inv_pose)
     s.cam_intr = (c_double * 9)(*[float(v) for v in np.asarray(ds.cam_intr).reshape(-1)])
-    s.depth = _p(ds.depth)
+    if ds.depth_raw is not None:
+        s.depth, s.depth_raw = None, _p(ds.depth_raw)
+        s.depth_h, s.depth_w = int(ds.depth_raw.shape[1]), int(ds.depth_raw.shape[2])
+    else:
+        s.depth, s.depth_raw = _p(ds.depth), None
     for k in ("depth_index", "frame_mask", "frame_rowbase", "frame_nmask", "frame_flags", "run_start", "run_end",
               "mask_run_offs", "view_mask_offs", "label_id"):
         setattr(s, k, _p(getattr(ds, k)))

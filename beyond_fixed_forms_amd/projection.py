@@ -241,7 +241,7 @@ def _projection_front(ds, cfg, debug_out, timers) -> _Front:
     # the sweep flags, per row, the 512-point chunks it stores into: the later passes read nothing else
     cmask_in = fr.cmask = _lib.chunk_mask_buffer(ds.n_rows, nw, dev).zero_() if (ds.n_rows and n_mviews) else None
     with sweep_span(timers, "project_views"):
-        _lib.project_views(ds.xyz, n, ds.inv_pose[:n_frames], ds.cam_intr, ds.depth, ds.depth_index, ds.height,
+        _lib.project_views(ds.xyz, n, ds.inv_pose[:n_frames], ds.cam_intr, ds.sweep_depth, ds.depth_index, ds.height,
                            ds.width, DEPTH_THRESH, maskbits if n_mviews else None, ds.word_bits, ds.frame_mask,
                            ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows if ds.n_rows else None,
                            masked, viewed, segmap if n_mviews else None, cmask_in, ds.tile_bounds)

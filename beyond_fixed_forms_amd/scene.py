@@ -89,7 +89,7 @@ class DeviceScene:
     width: int
     cam_intr: np.ndarray                 # (3,3) float64, host (becomes kernel arguments)
     xyz: torch.Tensor                    # f64 [3][n_pad]
-    depth: torch.Tensor                  # f32 [n_depth][H*W]
+    depth: Optional[torch.Tensor]        # f32 [n_depth][H*W] metres, or None when depth_raw is resident instead
     # per kernel frame (mask frames in mask_2d order, then viewed-only frames)
     inv_pose: torch.Tensor               # f64 [F][16]
     depth_index: torch.Tensor            # i32 [F]
@@ -114,6 +114,21 @@ class DeviceScene:
     unsort: Optional[torch.Tensor] = None   # i32 [N]: position of original point o in the sorted cloud (None = unsorted)
     tile_bounds: Optional[torch.Tensor] = None   # f64 [tiles][6]: boxes of the sweep's point tiles (frustum culling)
     perm: Optional[torch.Tensor] = None     # i32 [N]: original index of sorted position s (inverse of `unsort`)
+    depth_raw: Optional[torch.Tensor] = None   # int16 [n_depth][hs][ws]: the uint16 millimetres of the depth PNGs; the
+                                               # sweep evaluates /1000 + the bilinear resize per point (P:432-436)
+
+    @property
+    def sweep_depth(self):
+        """What the projection sweep gathers from: the raw frames when resident, else the float32 (H, W) images."""
+        return self.depth_raw if self.depth_raw is not None else self.depth
+
+
+def keep_raw_depth() -> bool:
+    """Raw 16-bit depth stays resident as stored and is resized per point inside the sweep (default);
+    BFF_DEPTH_RESIZE_PASS=1 restores the separate scale + resize pass into float32 (H, W) images (the two are
+    bit-identical; the pass costs 8 x the bytes)."""
+    import os
+    return os.environ.get("BFF_DEPTH_RESIZE_PASS") != "1"
 
 
 def viewed_frame_ids(color_files, downsample_ratio):
@@ -123,7 +138,7 @@ def viewed_frame_ids(color_files, downsample_ratio):
     return [f[:-4] for f in files[::downsample_ratio]]
 
 
-def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True) -> DeviceScene:
+def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True, raw_depth_resident=None) -> DeviceScene:
     """Upload one scene.  `scene` is duck-typed like beyond_fixed_forms_amd.synthetic.SceneInputs
     (the reference's on-disk objects held in memory)."""
     dev = torch.device(device)
@@ -215,6 +230,7 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True)
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(dev)
 
     nf = len(inv)
+    raw_keep = None
 
     def frames_to_device(frames, np_dtype, torch_dtype):
         """list of equally shaped host arrays -> one device tensor [F][...], frame by frame (no 1.5 GB np.stack:
@@ -234,7 +250,10 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True)
         if (hs, ws) != (h, w):
             taps = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in bilinear_taps(hs, ws, h, w))
         raw_dev = frames_to_device([d.view(np.int16) for d in depth_list], np.int16, torch.int16)
-        depth_dev = _lib.depth_from_u16(raw_dev, h, w, taps)
+        if keep_raw_depth() if raw_depth_resident is None else raw_depth_resident:
+            depth_dev, raw_keep = None, raw_dev
+        else:
+            depth_dev = _lib.depth_from_u16(raw_dev, h, w, taps)
     elif depth_list:
         depth_dev = frames_to_device(depth_list, np.float32, torch.float32)
     else:
@@ -257,4 +276,4 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True)
         view_mask_offs=t(np.array(view_mask_offs, np.int32), torch.int32),
         conf=conf.to(dev), labels=labels, label_id=t(label_id, torch.int32), n_label_ids=max(1, len(ids)),
         stage1=getattr(scene, "stage1", None), unsort=None if unsort is None else t(unsort, torch.int32),
-        perm=None if perm is None else t(perm.astype(np.int32), torch.int32))
+        perm=None if perm is None else t(perm.astype(np.int32), torch.int32), depth_raw=raw_keep)

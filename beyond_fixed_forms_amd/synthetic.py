@@ -256,6 +256,18 @@ def make_scene(shape="c1", seed: int = 0, device="cpu", query: str = "table", n_
                        height=h, width=w, point_object=obj)
 
 
+def with_sensor_depth(scene: SceneInputs, factor: int = 2) -> SceneInputs:
+    """The same scene with its depth frames as the 16-bit PNGs of a sensor with 1/factor of the working resolution
+    hold them (ScanNet: 480x640 depth for 968x1296 colour): `depths_raw` = every factor-th pixel in millimetres.  The
+    float32 (H, W) images are dropped: the device path resizes per point inside the sweep (P:431-436)."""
+    import copy
+    out = copy.copy(scene)
+    out.depths_raw = {f: np.ascontiguousarray(np.round(d[::factor, ::factor].astype(np.float64) * 1000.0).astype(np.uint16))
+                      for f, d in scene.depths.items()}
+    out.depths = {}
+    return out
+
+
 def _make_stage1(rng, xyz, obj, n_obj, query, n_stage1):
     """Open3DIS-like stage-1 dict: the cuboids' point sets + random box crops, 1-D RLE."""
     from .labels import SCANNET200_LABELS

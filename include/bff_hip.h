@@ -132,6 +132,22 @@ int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
                       uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
                       int32_t *masked_count, int32_t *viewed_count, const double *tile_bounds, void *stream);
 
+/* The same sweep with the depth frames resident as the PNGs store them (P:431-436): depth_raw uint16
+ * [n_depth][depth_h][depth_w] millimetres at the sensor's resolution.  `astype(float32) / 1000` and the bilinear resize
+ * to (height, width) are evaluated per point at the pixel it projects to, with exactly the float32 operations of
+ * bff_depth_from_u16 (tap coefficients as io._axis_taps: float64 source coordinate cast to float32 before its floor is
+ * subtracted, border columns copied, row indices clamped) -- results are bit-identical to bff_depth_from_u16 followed by
+ * bff_project_views, the (height, width) float32 images (8 x the bytes) are never built.  height < 2^15, width < 2^16. */
+int bff_project_views_u16(const double *xyz, int64_t n_points, int64_t n_pad,
+                          const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
+                          const uint16_t *depth_raw, int32_t depth_h, int32_t depth_w,
+                          const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
+                          const void *maskbits, const uint8_t *labels, const uint32_t *segmap, int32_t word_bits,
+                          const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
+                          const int32_t *frame_flags,
+                          uint64_t *rows, int64_t n_rows, int64_t nw, uint64_t *chunk_mask,
+                          int32_t *masked_count, int32_t *viewed_count, const double *tile_bounds, void *stream);
+
 /* Frustum culling for bff_project_views (optional, exact).  bounds: float64 [ceil(n_points / bff_point_tile_size())][6]
  * = (xmin, ymin, zmin, xmax, ymax, zmax) of every tile of bff_point_tile_size() consecutive points -- the points
  * one wave of the sweep owns.  Given the table, a wave skips a frame when the box of its points cannot contain a
@@ -459,7 +475,8 @@ typedef struct bff_scene {
     const double *tile_bounds;      /* bff_point_tile_bounds table or NULL */
     const double *inv_pose;         /* [n_frames][16] */
     double cam_intr[9];
-    const float *depth;
+    const float *depth;             /* [n_depth][height * width] metres, or NULL when depth_raw is given */
+    const uint16_t *depth_raw;      /* [n_depth][depth_h][depth_w] millimetres as stored (bff_project_views_u16), or NULL */
     const int32_t *depth_index, *frame_mask, *frame_rowbase, *frame_nmask, *frame_flags;   /* [n_frames] */
     const int32_t *run_start, *run_end, *mask_run_offs, *view_mask_offs;                     /* 2-D RLE run tables */
     const void *conf;               /* [n_rows] float16 / float32 */
@@ -467,7 +484,7 @@ typedef struct bff_scene {
     const int32_t *unsort;          /* [n_points] position of original point o in the sorted cloud, or NULL */
     const int32_t *perm;            /* [n_points] original index of sorted position s (inverse of unsort), or NULL */
     const int32_t *s1_run_start, *s1_run_end, *s1_row_run_offs;     /* stage-1 run tables or NULL */
-    int32_t height, width, n_frames, n_mviews, word_bits, n_rows, conf_f16, n_label_ids, s1_rows, pad_;
+    int32_t height, width, n_frames, n_mviews, word_bits, n_rows, conf_f16, n_label_ids, s1_rows, depth_h, depth_w, pad_;
 } bff_scene;
 
 typedef struct bff_scene_params {
@@ -545,6 +562,14 @@ int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t n_pad, con
                          int32_t height, int32_t width, double depth_thresh, const uint32_t *segmap, int32_t word_bits,
                          const int32_t *frame_mask, uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words,
                          uint32_t *label_lines, void *stream);
+/* The same for bff_project_views_u16: depth_lines counts the 128-byte lines of the uint16 source frames (64 texels
+ * per line; line_words >= ceil(ceil(depth_h * depth_w / 64) / 32) as well). */
+int bff_diag_sweep_lines_u16(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
+                             const double *cam_intr_host, int32_t n_frames, const uint16_t *depth_raw, int32_t depth_h,
+                             int32_t depth_w, const int32_t *depth_index, int32_t height, int32_t width,
+                             double depth_thresh, const uint32_t *segmap, int32_t word_bits, const int32_t *frame_mask,
+                             uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words, uint32_t *label_lines,
+                             void *stream);
 /* Measurement aid: n_lanes lanes each read one float at element lane * stride of src (every element once per launch)
  * -- a gather with a known number of distinct cache lines, to calibrate the FETCH_SIZE counter (scripts/diag_membw.py). */
 int bff_diag_gather(const float *src, int64_t n_lanes, int64_t stride, float *out, void *stream);

@@ -67,6 +67,23 @@ def test_checksums_and_layout_invariance(c2):
     assert torch.equal(rows_a, raw) and torch.equal(m_a, masked) and torch.equal(v_a, viewed)
 
 
+def test_raw_depth_in_the_sweep_equals_the_resize_pass(c2):
+    """Config 2 with the depth frames resident as 16-bit half-resolution images (the stored format, P:431-436): the
+    sweep's per-point /1000 + bilinear resize gives rows and counters bit-identical to the separate resize pass
+    into float32 (H, W) images followed by the float32 sweep."""
+    from beyond_fixed_forms_amd.projection import run_projection
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    from beyond_fixed_forms_amd.synthetic import with_sensor_depth
+    scene, cfg, _ = c2
+    raw = with_sensor_depth(scene)
+    a = run_projection(prepare_scene(raw, cfg, device=DEV, raw_depth_resident=True), cfg, debug_out=True)
+    b = run_projection(prepare_scene(raw, cfg, device=DEV, raw_depth_resident=False), cfg, debug_out=True)
+    for k in ("raw_rows", "masked_counts_raw", "viewed_counts"):
+        assert torch.equal(a.debug[k], b.debug[k]), k
+    assert int(a.debug["masked_counts_raw"].sum().item()) > 10 ** 6
+    assert a.groups == b.groups and torch.equal(a.rows, b.rows) and torch.equal(a.conf, b.conf)
+
+
 def test_components_two_formulations_agree(c2):
     """Union-find tile pass (production) == adjacency matrix + label propagation (cross-check), Ins = 9000."""
     from beyond_fixed_forms_amd import _lib

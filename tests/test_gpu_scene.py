@@ -543,6 +543,14 @@ def test_overlapped_ingestion_equals_prepare_scene(api):
     raw.depths_raw = {f: np.ascontiguousarray(np.round(d[::2, ::2].astype(np.float64) * 1000).astype(np.uint16))
                       for f, d in raw.depths.items()}
     a, b = prepare_scene(raw, cfg, device=DEV), ingest.prepare_scene_fast(raw, cfg, device=DEV)
+    assert a.depth is None and b.depth is None and torch.equal(a.depth_raw, b.depth_raw)      # resident as stored
+    assert tuple(a.depth_raw.shape[1:]) == (cfg.height_2d // 2, cfg.width_2d // 2)
+    monkey_env = dict(os.environ)
+    os.environ["BFF_DEPTH_RESIZE_PASS"] = "1"                # the separate scale + resize pass: float32 (H, W) images
+    try:
+        a, b = prepare_scene(raw, cfg, device=DEV), ingest.prepare_scene_fast(raw, cfg, device=DEV)
+    finally:
+        os.environ.clear(); os.environ.update(monkey_env)
     assert torch.equal(a.depth, b.depth) and a.depth.shape[1] == cfg.height_2d * cfg.width_2d
     # loader threads: results through the pipeline == results of the plain path == oracle
     ing = ingest.Ingestor(cfg, DEV, n_loaders=2, native_threads=2)
@@ -578,3 +586,70 @@ def test_value_set_threshold_in_the_scene_call(api, monkeypatch):
         assert a.debug["path"] == b.debug["path"] == "fast"
         assert np.float32(a.debug["thr"]).tobytes() == np.float32(b.debug["thr"]).tobytes()
         assert torch.equal(a.rows, b.rows) and torch.equal(a.conf, b.conf) and list(a.groups) == list(b.groups)
+
+
+RAW_DEPTH_CASES = {
+    # scene keywords, size of the stored 16-bit depth frames (None: same size as the working image)
+    "half": (dict(shape="tiny", seed=80), lambda h, w: (h // 2, w // 2)),
+    "same_size": (dict(shape="tiny", seed=81), None),
+    "scannet_ratio": (dict(shape="c1", seed=82, n_views=4), lambda h, w: (240, 320)),
+    "odd_ratio_up": (dict(shape="tiny", seed=83, height=97, width=131), lambda h, w: (41, 67)),
+    "down_and_up": (dict(shape="tiny", seed=84), lambda h, w: (h * 2 + 3, w - 29)),     # rows shrink, columns stretch
+    "one_row_source": (dict(shape="tiny", seed=85), lambda h, w: (1, 2)),
+}
+
+
+@pytest.mark.parametrize("case", list(RAW_DEPTH_CASES))
+def test_sweep_resizes_raw_depth_per_point(api, case):
+    """Depth resident as the PNGs store it (uint16, sensor resolution): the sweep evaluates /1000 + the bilinear resize
+    at the pixel each point projects to (bff_project_views_u16).  Raw rows, both counters and the final masks are
+    bit-identical (a) to the two-step path (bff_depth_from_u16 into float32 (H, W) images, then the sweep) and (b) to
+    the oracle fed with the host restatement of the resize (io.resize_bilinear_f32; cv2 itself is unpinned) -- on
+    the step-by-step path and on the one-call production path."""
+    import copy
+    projection, refinement = api
+    from beyond_fixed_forms_amd.ingest import prepare_scene_fast
+    from beyond_fixed_forms_amd.io import resize_bilinear_f32
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    from beyond_fixed_forms_amd.synthetic import make_scene
+    kw, size = RAW_DEPTH_CASES[case]
+    scene = make_scene(**kw)
+    h, w = scene.height, scene.width
+    rng = np.random.default_rng(7)
+    raw = copy.copy(scene)
+    raw.depths_raw = {}
+    for f, d in scene.depths.items():
+        mm = np.round(d.astype(np.float64) * 1000).astype(np.uint16)
+        if size is not None:
+            hs, ws = size(h, w)
+            yy = np.minimum((np.arange(hs) * h) // hs, h - 1)
+            xx = np.minimum((np.arange(ws) * w) // ws, w - 1)
+            mm = np.ascontiguousarray(mm[yy][:, xx])
+            mm[rng.random(mm.shape) < 0.02] = 0                                   # sensor holes
+        raw.depths_raw[f] = mm
+    host = copy.copy(scene)                       # what the reference would hold after cv2.imread / 1000 + cv2.resize
+    host.depths = {f: resize_bilinear_f32(m.astype(np.float32) / np.float32(1000), w, h) for f, m in raw.depths_raw.items()}
+    cfg = cfg_for(scene)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp, dbg = pref.project_scene_ref(host, cfg, return_debug=True)
+    ds_raw = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=True)
+    ds_two = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=False)
+    assert ds_raw.depth is None and ds_raw.depth_raw is not None and ds_two.depth_raw is None
+    from beyond_fixed_forms_amd.scene import viewed_frame_ids
+    slots = list(dict.fromkeys([fr["frame_id"][:-4] for fr in raw.mask_2d] + viewed_frame_ids(raw.color_files, cfg.downsample_ratio)))
+    host_depth = torch.from_numpy(np.stack([host.depths[f].reshape(-1) for f in slots]))
+    assert torch.equal(ds_two.depth.cpu(), host_depth)                            # device resize pass == host restatement
+    a = projection.run_projection(ds_raw, cfg, debug_out=True)
+    b = projection.run_projection(ds_two, cfg, debug_out=True)
+    for k in ("raw_rows", "masked_counts_raw", "viewed_counts"):
+        assert torch.equal(a.debug[k], b.debug[k]), k
+    n = scene.points.shape[0]
+    rawbits = np.unpackbits(a.debug["raw_rows"].cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[:, :n].astype(bool)
+    assert np.array_equal(rawbits, dbg["raw_ins"].numpy())
+    assert np.array_equal(a.debug["viewed_counts"].cpu().numpy(), dbg["viewed_counts"].numpy().astype(np.int32))
+    same(a.to_dict(), exp)
+    same(b.to_dict(), exp)
+    prod = projection.projection_back(projection.projection_front(prepare_scene_fast(raw, cfg, DEV), cfg))   # one native call
+    assert prod.debug["path"] == "fast"
+    same(prod.to_dict(), exp)
