@@ -282,14 +282,16 @@ def compulsory_traffic(ds, dev):
     del maskbits, labels
     line_words = (((hw + 15) // 16 + 31) // 32 + 1) // 2 * 2
     if ds.depth_raw is not None:
-        line_words = max(line_words, (((ds.depth_raw.shape[1] * ds.depth_raw.shape[2] + 63) // 64 + 31) // 32 + 1) // 2 * 2)
+        per_frame = ds.depth_raw.shape[1] * (ds.depth_raw.shape[2] if ds.depth_raw.dim() == 3 else 1)
+        line_words = max(line_words, (((per_frame + 63) // 64 + 31) // 32 + 1) // 2 * 2)
     dl = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
     ml = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
     ll = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
     k = (ctypes.c_double * 9)(*[float(v) for v in ds.cam_intr.reshape(-1)])
     if ds.depth_raw is not None:
         _lib.call("bff_diag_sweep_lines_u16", _lib._ptr(ds.xyz), n, ds.xyz.shape[1], _lib._ptr(ds.inv_pose), ctypes.cast(k, ctypes.c_void_p),
-                  ds.n_frames, _lib._ptr(ds.depth_raw), ds.depth_raw.shape[1], ds.depth_raw.shape[2], _lib._ptr(ds.depth_index),
+                  ds.n_frames, _lib._ptr(ds.depth_raw), *(ds.depth_size if ds.depth_size is not None else ds.depth_raw.shape[1:3]),
+                  0 if ds.depth_size is None else 1, _lib._ptr(ds.depth_index),
                   ds.height, ds.width, 0.08, _lib._ptr(segmap), ds.word_bits, _lib._ptr(ds.frame_mask), _lib._ptr(dl), _lib._ptr(ml),
                   line_words, _lib._ptr(ll))
     else:
@@ -550,7 +552,8 @@ def main():
                                    f"{ds.n_viewed} viewed frames @{h}x{w}, {m} masks/view (Ins={ds.n_rows}), "
                                    f"stage-1 S1={len(scenes[0].stage1['ins'])}, 198x768 f16 text bank; inputs RESIDENT in "
                                    f"HBM (uploaded before the timed region); depth " +
-                                   (f"as stored (uint16 mm, {ds.depth_raw.shape[1]}x{ds.depth_raw.shape[2]}), /1000 + bilinear resize "
+                                   (f"as stored (uint16 mm, {'x'.join(str(int(v)) for v in (ds.depth_size or ds.depth_raw.shape[1:3]))}"
+                                    f"{', 8x8-texel tiles' if ds.depth_size else ''}), /1000 + bilinear resize "
                                     f"per point inside the sweep" if ds.depth_raw is not None else "float32 (H, W)") +
                                    f"; {n_scenes} different scenes rotate through the loop",
                        "scenes_per_step": world, "priming_steps_in_setup": priming,

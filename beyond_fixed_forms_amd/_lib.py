@@ -24,7 +24,8 @@ SIGNATURES = {
     "bff_rle_to_maskbits": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P],
     "bff_rle_to_labels": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P],
     "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P],
-    "bff_project_views_u16": [_P, _L, _L, _P, _P, _I, _P, _I, _I, _P, _I, _I, _D, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P],
+    "bff_depth_tile_u16": [_P, _I, _I, _I, _P, _P],
+    "bff_project_views_u16": [_P, _L, _L, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _D, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P],
     "bff_point_tile_bounds": [_P, _L, _L, _P, _P],
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
     "bff_cross_popcount": [_P, _P, _I, _P, _P, _I, _L, _P, _P],
@@ -62,7 +63,7 @@ SIGNATURES = {
     "bff_scene_project": [_P, _P, _P, _P],
     "bff_diag_gather": [_P, _L, _L, _P, _P],
     "bff_diag_sweep_lines": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _I, _P, _P, _P, _L, _P, _P],
-    "bff_diag_sweep_lines_u16": [_P, _L, _L, _P, _P, _I, _P, _I, _I, _P, _I, _I, _D, _P, _I, _P, _P, _P, _L, _P, _P],
+    "bff_diag_sweep_lines_u16": [_P, _L, _L, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _D, _P, _I, _P, _P, _P, _L, _P, _P],
     "bff_scatter_bits": [_P, _I, _L, _P, _L, _L, _P, _P, _P],
     "bff_cross_popcount_dev": [_P, _I, _P, _I, _L, _P, _P, _I, _I, _P],
     "bff_cloud_layout": [_P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -72,13 +73,13 @@ SIGNATURES = {
 }
 PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, []), "bff_arch": (ctypes.c_char_p, []),
          "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_label_plane_stride": (c_int64, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
-         "bff_point_tile_size": (c_int32, []), "bff_merge_scratch_words": (c_int64, [c_int32]), "bff_merge_uses_chunk_bound": (c_int32, [c_int64]),
+         "bff_point_tile_size": (c_int32, []), "bff_depth_tiled_texels": (c_int64, [c_int32, c_int32]), "bff_merge_scratch_words": (c_int64, [c_int32]), "bff_merge_uses_chunk_bound": (c_int32, [c_int64]),
          "bff_profile_next_merge": (c_int32, [_P, _P]), "bff_group_slice_cap": (c_int32, [c_int32, c_int32]),
          "bff_resolve_overlaps_scratch_words": (c_int64, []), "bff_point_threshold_scratch_words": (c_int64, []), "bff_scene_header_words": (c_int32, [c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
          "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
          "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class BffLibraryError(RuntimeError):
@@ -207,15 +208,18 @@ def rle_to_labels(run_start, run_end, mask_run_offs, view_mask_offs, n_views, n_
 
 def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, height, width, depth_thresh,
                   maskbits, word_bits, frame_mask, frame_rowbase, frame_nmask, frame_flags,
-                  rows, masked_count, viewed_count, segmap=None, chunk_mask=None, tile_bounds=None, labels=None):
+                  rows, masked_count, viewed_count, segmap=None, chunk_mask=None, tile_bounds=None, labels=None,
+                  depth_size=None):
     """depth: float32 [n_depth][H*W] metres, or int16 [n_depth][hs][ws] (the uint16 millimetres of the PNGs): then
-    /1000 + the bilinear resize to (height, width) are evaluated per point inside the sweep (bff_project_views_u16)."""
+    /1000 + the bilinear resize to (height, width) are evaluated per point inside the sweep (bff_project_views_u16).
+    depth_size = (hs, ws): `depth` is int16 [n_depth][depth_tiled_texels(hs, ws)], frames in 8 x 8 tiles (tile_depth)."""
     k = (c_double * 9)(*[float(v) for v in cam_intr.reshape(-1)])
     n_frames = inv_pose.shape[0]
     nw = (n_points + 63) // 64
     if depth.dtype == torch.int16:
+        hs, ws = (depth_size if depth_size is not None else depth.shape[1:3])
         head = ("bff_project_views_u16", _ptr(xyz_soa, f64), n_points, xyz_soa.shape[1], _ptr(inv_pose, f64),
-                ctypes.cast(k, c_void_p), n_frames, _ptr(depth, torch.int16), depth.shape[1], depth.shape[2])
+                ctypes.cast(k, c_void_p), n_frames, _ptr(depth, torch.int16), int(hs), int(ws), 0 if depth_size is None else 1)
     else:
         head = ("bff_project_views", _ptr(xyz_soa, f64), n_points, xyz_soa.shape[1], _ptr(inv_pose, f64),
                 ctypes.cast(k, c_void_p), n_frames, _ptr(depth, f32))
@@ -224,6 +228,15 @@ def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, hei
          _ptr(frame_nmask, i32), _ptr(frame_flags, i32), _ptr(rows, i64),
          0 if rows is None else rows.shape[0], nw, _ptr(chunk_mask, i64), _ptr(masked_count, i32),
          _ptr(viewed_count, i32), _ptr(tile_bounds, f64))
+
+
+def tile_depth(raw):
+    """int16 [F][hs][ws] (uint16 millimetres as stored) -> [F][tiled texels]: every frame in 8 x 8-texel tiles of 128
+    bytes (bff_depth_tile_u16), the layout the sweep gathers its taps from."""
+    f, hs, ws = raw.shape
+    out = torch.empty((f, int(load().bff_depth_tiled_texels(hs, ws))), dtype=torch.int16, device=raw.device)
+    call("bff_depth_tile_u16", _ptr(raw, torch.int16), f, hs, ws, _ptr(out, torch.int16))
+    return out
 
 
 def point_tile_bounds(xyz_soa, n_points):

@@ -31,6 +31,9 @@ struct Intrinsics { double k[9]; };
 // (H, W) float image (8x the bytes of the source) is never built.  hs == H and ws == W: the resize is the identity.
 struct RawDepth {
     int hs, ws;                 // source size
+    int tw;                     // > 0: frames are stored in 8 x 8-texel tiles of 128 bytes, tw tiles per tile row
+                                // (bff_depth_tile_u16): texel (y, x) sits at ((y >> 3) * tw + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7)
+    int64_t frame_stride;       // texels per frame (padded to whole tiles when tiled)
     int same;                   // source size == (H, W)
     float scale;                // 1000
     double sx, sy;              // 1 / (W / ws), 1 / (H / hs) in float64, as io._axis_taps computes them
@@ -55,6 +58,11 @@ __device__ __forceinline__ void axis_tap(int d, double scale, int n_src, int &i0
         i1 = min(max(s + 1, 0), n_src - 1);
         i0 = min(max(s, 0), n_src - 1);
     }
+}
+
+__device__ __forceinline__ int64_t raw_texel(const RawDepth &r, int y, int x)
+{
+    return r.tw ? ((int64_t)(y >> 3) * r.tw + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7) : (int64_t)y * r.ws + x;
 }
 
 // the resized depth value at one pixel from its four source texels (same operation order as depth_resize_kernel)
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
         if ((culled >> (8 * (f - f0))) & 1) continue;      // wave-uniform
         const double *P = inv_pose + 16 * (int64_t)f;
         const float *dimg = kRaw ? nullptr : reinterpret_cast<const float *>(depth) + (int64_t)depth_index[f] * hw;
-        const uint16_t *rimg = kRaw ? reinterpret_cast<const uint16_t *>(depth) + (int64_t)depth_index[f] * raw.hs * raw.ws
+        const uint16_t *rimg = kRaw ? reinterpret_cast<const uint16_t *>(depth) + (int64_t)depth_index[f] * raw.frame_stride
                                     : nullptr;
         const int mi = maskbits ? frame_mask[f] : -1;
         const bool has_masks = mi >= 0;
@@ -206,13 +214,13 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
                     // the four source texels of the pixel (two of them when the sizes agree): all in flight together
                     const int ux = pu[j] & 0xffff, vy = pu[j] >> 16;
                     if (raw.same) {
-                        t00[j] = rimg[pix[j]];
+                        t00[j] = rimg[raw_texel(raw, vy, ux)];
                     } else {
                         int x0, x1, y0, y1;
                         axis_tap<true>(ux, raw.sx, raw.ws, x0, x1, ta[j]);
                         axis_tap<false>(vy, raw.sy, raw.hs, y0, y1, tb[j]);
-                        const uint16_t *r0 = rimg + (int64_t)y0 * raw.ws, *r1 = rimg + (int64_t)y1 * raw.ws;
-                        t00[j] = r0[x0]; t01[j] = r0[x1]; t10[j] = r1[x0]; t11[j] = r1[x1];
+                        t00[j] = rimg[raw_texel(raw, y0, x0)]; t01[j] = rimg[raw_texel(raw, y0, x1)];
+                        t10[j] = rimg[raw_texel(raw, y1, x0)]; t11[j] = rimg[raw_texel(raw, y1, x1)];
                     }
                 } else {
                     dval[j] = dimg[pix[j]];
@@ -359,11 +367,12 @@ __global__ void sweep_lines_kernel(const double *__restrict__ xyz, int64_t n_poi
     const int pix = (int)v * W + (int)u;
     float d;
     if (is_raw) {                                                       // uint16 source texels: 64 per 128-B line
-        const uint16_t *img = reinterpret_cast<const uint16_t *>(depth) + (int64_t)depth_index[f] * raw.hs * raw.ws;
+        const uint16_t *img = reinterpret_cast<const uint16_t *>(depth) + (int64_t)depth_index[f] * raw.frame_stride;
         auto mark = [&](int y, int x) {
-            const int l = (y * raw.ws + x) >> 6;
+            const int64_t t = raw_texel(raw, y, x);
+            const int l = (int)(t >> 6);
             atomicOr(depth_lines + (int64_t)f * line_words + (l >> 5), 1u << (l & 31));
-            return img[(int64_t)y * raw.ws + x];
+            return img[t];
         };
         if (raw.same) {
             d = __fdiv_rn((float)mark((int)v, (int)u), raw.scale);
@@ -728,10 +737,46 @@ static int rle_decode(const int32_t *run_start, const int32_t *run_end, const in
     return launched("bff_rle_to_maskbits");
 }
 
-static RawDepth raw_depth_params(int32_t depth_h, int32_t depth_w, int32_t height, int32_t width)
+namespace bff {
+// uint16 frames [n][hs][ws] -> 8 x 8-texel tiles of 128 bytes, [n][ceil(hs/8)][ceil(ws/8)][8][8] (padding texels 0): the
+// 64 points of a wave project onto a compact patch of a frame, and the four taps of a point are neighbours in BOTH
+// directions -- in tiles they touch a fraction of the 128-byte lines that row-major frames make them touch.
+__global__ void depth_tile_kernel(const uint16_t *__restrict__ src, int hs, int ws, int th, int tw, uint16_t *__restrict__ dst)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // one destination texel
+    const int64_t per_frame = (int64_t)th * tw * 64;
+    if (t >= per_frame) return;
+    const int f = blockIdx.y;
+    const int tile = (int)(t >> 6), in = (int)(t & 63);
+    const int y = (tile / tw) * 8 + (in >> 3), x = (tile % tw) * 8 + (in & 7);
+    dst[(int64_t)f * per_frame + t] = (y < hs && x < ws) ? src[((int64_t)f * hs + y) * ws + x] : (uint16_t)0;
+}
+}  // namespace bff
+
+extern "C" int64_t bff_depth_tiled_texels(int32_t h_src, int32_t w_src)
+{
+    return (int64_t)((h_src + 7) / 8) * ((w_src + 7) / 8) * 64;
+}
+
+extern "C" int bff_depth_tile_u16(const uint16_t *src, int32_t n_frames, int32_t h_src, int32_t w_src, uint16_t *dst,
+                                  void *stream)
+{
+    BFF_REQUIRE(n_frames >= 0 && h_src > 0 && w_src > 0, "bff_depth_tile_u16: bad sizes");
+    if (n_frames == 0) return BFF_OK;
+    BFF_REQUIRE(src && dst, "bff_depth_tile_u16: null pointer");
+    BFF_LIMIT(n_frames <= 65535, "bff_depth_tile_u16: too many frames");
+    const int th = (h_src + 7) / 8, tw = (w_src + 7) / 8;
+    dim3 grid((unsigned)ceil_div((int64_t)th * tw * 64, 256), (unsigned)n_frames);
+    depth_tile_kernel<<<grid, 256, 0, as_stream(stream)>>>(src, h_src, w_src, th, tw, dst);
+    return launched("bff_depth_tile_u16");
+}
+
+static RawDepth raw_depth_params(int32_t depth_h, int32_t depth_w, int32_t height, int32_t width, int32_t tiled)
 {
     RawDepth r;
     r.hs = depth_h; r.ws = depth_w;
+    r.tw = tiled ? (depth_w + 7) / 8 : 0;
+    r.frame_stride = tiled ? (int64_t)((depth_h + 7) / 8) * r.tw * 64 : (int64_t)depth_h * depth_w;
     r.same = depth_h == height && depth_w == width;
     r.scale = 1000.0f;                                                  // depth_scale, hard-coded at P:346
     r.sx = 1.0 / ((double)width / (double)depth_w);                     // io._axis_taps: 1 / (n_dst / n_src)
@@ -811,7 +856,7 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
 
 extern "C" int bff_project_views_u16(const double *xyz, int64_t n_points, int64_t n_pad,
                                      const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
-                                     const uint16_t *depth_raw, int32_t depth_h, int32_t depth_w,
+                                     const uint16_t *depth_raw, int32_t depth_h, int32_t depth_w, int32_t depth_tiled,
                                      const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
                                      const void *maskbits, const uint8_t *labels, const uint32_t *segmap, int32_t word_bits,
                                      const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
@@ -820,7 +865,7 @@ extern "C" int bff_project_views_u16(const double *xyz, int64_t n_points, int64_
                                      int32_t *masked_count, int32_t *viewed_count, const double *tile_bounds,
                                      void *stream)
 {
-    const RawDepth raw = raw_depth_params(depth_h, depth_w, height, width);
+    const RawDepth raw = raw_depth_params(depth_h, depth_w, height, width, depth_tiled);
     return project_views_launch(xyz, n_points, n_pad, inv_pose, cam_intr_host, n_frames, depth_raw, &raw, depth_index, height,
                                 width, depth_thresh, maskbits, labels, segmap, word_bits, frame_mask, frame_rowbase,
                                 frame_nmask, frame_flags, rows, n_rows, nw, chunk_mask, masked_count, viewed_count,
@@ -882,13 +927,13 @@ extern "C" int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t
 
 extern "C" int bff_diag_sweep_lines_u16(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
                                         const double *cam_intr_host, int32_t n_frames, const uint16_t *depth_raw,
-                                        int32_t depth_h, int32_t depth_w,
+                                        int32_t depth_h, int32_t depth_w, int32_t depth_tiled,
                                         const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
                                         const uint32_t *segmap, int32_t word_bits, const int32_t *frame_mask,
                                         uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words,
                                         uint32_t *label_lines, void *stream)
 {
-    const RawDepth raw = raw_depth_params(depth_h, depth_w, height, width);
+    const RawDepth raw = raw_depth_params(depth_h, depth_w, height, width, depth_tiled);
     return diag_sweep_lines(xyz, n_points, n_pad, inv_pose, cam_intr_host, n_frames, depth_raw, &raw, depth_index, height, width,
                             depth_thresh, segmap, word_bits, frame_mask, depth_lines, mask_lines, line_words, label_lines, stream);
 }

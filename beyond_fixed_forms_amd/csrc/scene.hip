@@ -71,7 +71,7 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     BFF_ZERO(hdr, sizeof(int32_t) * BFF_HDR_SIZES);
     if (sc->depth_raw)          // depth as the PNGs store it: /1000 + bilinear resize per point inside the sweep
         BFF_TRY(bff_project_views_u16(sc->xyz, n, sc->n_pad, sc->inv_pose, sc->cam_intr, sc->n_frames, sc->depth_raw,
-                                      sc->depth_h, sc->depth_w, sc->depth_index, sc->height, sc->width, pr->depth_thresh,
+                                      sc->depth_h, sc->depth_w, sc->depth_tiled, sc->depth_index, sc->height, sc->width, pr->depth_thresh,
                                       ws->maskbits, ws->labels, ws->segmap, sc->word_bits, sc->frame_mask, sc->frame_rowbase,
                                       sc->frame_nmask, sc->frame_flags, ws->rows, n_rows, nw, ws->chunk_mask, ws->masked,
                                       ratio ? ws->viewed : nullptr, sc->tile_bounds, stream));

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .scene import DeviceScene, keep_raw_depth, prepare_scene, viewed_frame_ids
+from .scene import DeviceScene, keep_raw_depth, prepare_scene, tile_raw_depth, viewed_frame_ids
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libbff_host.so")
@@ -177,7 +177,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
         inv = np.zeros((0, 16))
 
     # ---- depth: frames packed into pinned staging by native threads, ONE asynchronous copy
-    raw_keep = None
+    raw_keep = raw_size = None
     raw_depth = getattr(scene, "depths_raw", None)
     src = raw_depth if raw_depth is not None else scene.depths
     frames = [src[f] for f in depth_ids]
@@ -198,6 +198,8 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
             raw_dev = flat.view(torch.int16).view(len(frames), hs, ws_).to(dev, non_blocking=True)
             if keep_raw_depth():                     # resident as stored: the sweep resizes per point
                 depth_dev, raw_keep = None, raw_dev
+                if tile_raw_depth():
+                    raw_keep, raw_size = _lib.tile_depth(raw_dev), (hs, ws_)
             else:
                 taps = None
                 if (hs, ws_) != (h, w):
@@ -261,7 +263,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
         frame_flags=f_flags_d, n_frames=nf, n_mask_frames=n_mask_frames, n_viewed=len(viewed), word_bits=word_bits,
         n_rows=row, run_start=run_start, run_end=run_end, mask_run_offs=run_offs, view_mask_offs=vmo_d, conf=conf_d,
         labels=labels, label_id=label_d, n_label_ids=max(1, len(ids)), stage1=getattr(scene, "stage1", None),
-        unsort=unsort[:n] if sort else None, perm=perm if sort else None, depth_raw=raw_keep)
+        unsort=unsort[:n] if sort else None, perm=perm if sort else None, depth_raw=raw_keep, depth_size=raw_size)
 
 
 _taps = {}

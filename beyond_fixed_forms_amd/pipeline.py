@@ -33,7 +33,7 @@ class SceneStruct(ctypes.Structure):
                 ("s1_run_start", c_void_p), ("s1_run_end", c_void_p), ("s1_row_run_offs", c_void_p),
                 ("height", c_int32), ("width", c_int32), ("n_frames", c_int32), ("n_mviews", c_int32),
                 ("word_bits", c_int32), ("n_rows", c_int32), ("conf_f16", c_int32), ("n_label_ids", c_int32),
-                ("s1_rows", c_int32), ("depth_h", c_int32), ("depth_w", c_int32), ("pad_", c_int32)]
+                ("s1_rows", c_int32), ("depth_h", c_int32), ("depth_w", c_int32), ("depth_tiled", c_int32)]
 
 
 class ParamsStruct(ctypes.Structure):
@@ -104,7 +104,8 @@ def scene_struct(ds, stage1=None, n_frames=None):
     s.cam_intr = (c_double * 9)(*[float(v) for v in np.asarray(ds.cam_intr).reshape(-1)])
     if ds.depth_raw is not None:
         s.depth, s.depth_raw = None, _p(ds.depth_raw)
-        s.depth_h, s.depth_w = int(ds.depth_raw.shape[1]), int(ds.depth_raw.shape[2])
+        hs, ws = ds.depth_size if ds.depth_size is not None else ds.depth_raw.shape[1:3]
+        s.depth_h, s.depth_w, s.depth_tiled = int(hs), int(ws), 0 if ds.depth_size is None else 1
     else:
         s.depth, s.depth_raw = _p(ds.depth), None
     for k in ("depth_index", "frame_mask", "frame_rowbase", "frame_nmask", "frame_flags", "run_start", "run_end",

@@ -244,7 +244,7 @@ def _projection_front(ds, cfg, debug_out, timers) -> _Front:
         _lib.project_views(ds.xyz, n, ds.inv_pose[:n_frames], ds.cam_intr, ds.sweep_depth, ds.depth_index, ds.height,
                            ds.width, DEPTH_THRESH, maskbits if n_mviews else None, ds.word_bits, ds.frame_mask,
                            ds.frame_rowbase, ds.frame_nmask, ds.frame_flags, rows if ds.n_rows else None,
-                           masked, viewed, segmap if n_mviews else None, cmask_in, ds.tile_bounds)
+                           masked, viewed, segmap if n_mviews else None, cmask_in, ds.tile_bounds, depth_size=ds.depth_size)
     del maskbits
     # a14/a15: point filter (P:512-583), entirely on the device: the threshold never visits the host
     if cfg.if_occurance_threshold or do_ratio:

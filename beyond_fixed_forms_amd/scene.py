@@ -114,13 +114,21 @@ class DeviceScene:
     unsort: Optional[torch.Tensor] = None   # i32 [N]: position of original point o in the sorted cloud (None = unsorted)
     tile_bounds: Optional[torch.Tensor] = None   # f64 [tiles][6]: boxes of the sweep's point tiles (frustum culling)
     perm: Optional[torch.Tensor] = None     # i32 [N]: original index of sorted position s (inverse of `unsort`)
-    depth_raw: Optional[torch.Tensor] = None   # int16 [n_depth][hs][ws]: the uint16 millimetres of the depth PNGs; the
-                                               # sweep evaluates /1000 + the bilinear resize per point (P:432-436)
+    depth_raw: Optional[torch.Tensor] = None   # int16: the uint16 millimetres of the depth PNGs, [n_depth][hs][ws] or --
+                                               # depth_size given -- [n_depth][tiled texels] in 8 x 8 tiles; the sweep
+                                               # evaluates /1000 + the bilinear resize per point (P:432-436)
+    depth_size: Optional[tuple] = None         # (hs, ws) of the tiled frames
 
     @property
     def sweep_depth(self):
         """What the projection sweep gathers from: the raw frames when resident, else the float32 (H, W) images."""
         return self.depth_raw if self.depth_raw is not None else self.depth
+
+
+def tile_raw_depth() -> bool:
+    """Resident raw depth is re-laid in 8 x 8-texel tiles (default; BFF_DEPTH_TILES=0: row-major as stored)."""
+    import os
+    return os.environ.get("BFF_DEPTH_TILES") != "0"
 
 
 def keep_raw_depth() -> bool:
@@ -230,7 +238,7 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True,
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(dev)
 
     nf = len(inv)
-    raw_keep = None
+    raw_keep = raw_size = None
 
     def frames_to_device(frames, np_dtype, torch_dtype):
         """list of equally shaped host arrays -> one device tensor [F][...], frame by frame (no 1.5 GB np.stack:
@@ -252,6 +260,8 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True,
         raw_dev = frames_to_device([d.view(np.int16) for d in depth_list], np.int16, torch.int16)
         if keep_raw_depth() if raw_depth_resident is None else raw_depth_resident:
             depth_dev, raw_keep = None, raw_dev
+            if tile_raw_depth():
+                raw_keep, raw_size = _lib.tile_depth(raw_dev), (hs, ws)
         else:
             depth_dev = _lib.depth_from_u16(raw_dev, h, w, taps)
     elif depth_list:
@@ -276,4 +286,4 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True,
         view_mask_offs=t(np.array(view_mask_offs, np.int32), torch.int32),
         conf=conf.to(dev), labels=labels, label_id=t(label_id, torch.int32), n_label_ids=max(1, len(ids)),
         stage1=getattr(scene, "stage1", None), unsort=None if unsort is None else t(unsort, torch.int32),
-        perm=None if perm is None else t(perm.astype(np.int32), torch.int32), depth_raw=raw_keep)
+        perm=None if perm is None else t(perm.astype(np.int32), torch.int32), depth_raw=raw_keep, depth_size=raw_size)

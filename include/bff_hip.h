@@ -32,7 +32,7 @@ extern "C" {
 #define BFF_E_ARG (-1)      /* null pointer / negative size / unsupported parameter */
 #define BFF_E_LIMIT (-2)    /* size beyond what a kernel supports (documented per call) */
 
-#define BFF_ABI_VERSION 4
+#define BFF_ABI_VERSION 5
 
 int bff_abi_version(void);
 const char *bff_last_error(void);
@@ -137,10 +137,14 @@ int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
  * to (height, width) are evaluated per point at the pixel it projects to, with exactly the float32 operations of
  * bff_depth_from_u16 (tap coefficients as io._axis_taps: float64 source coordinate cast to float32 before its floor is
  * subtracted, border columns copied, row indices clamped) -- results are bit-identical to bff_depth_from_u16 followed by
- * bff_project_views, the (height, width) float32 images (8 x the bytes) are never built.  height < 2^15, width < 2^16. */
+ * bff_project_views, the (height, width) float32 images (8 x the bytes) are never built.  height < 2^15, width < 2^16.
+ * depth_tiled != 0: the frames are stored in 8 x 8-texel tiles (bff_depth_tile_u16) -- same values, fewer 128-byte lines
+ * per wave: a wave's points project onto a compact patch and a point's four taps are neighbours in both directions. */
+int64_t bff_depth_tiled_texels(int32_t h_src, int32_t w_src);      /* texels of one tiled frame (padded to whole tiles) */
+int bff_depth_tile_u16(const uint16_t *src, int32_t n_frames, int32_t h_src, int32_t w_src, uint16_t *dst, void *stream);
 int bff_project_views_u16(const double *xyz, int64_t n_points, int64_t n_pad,
                           const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
-                          const uint16_t *depth_raw, int32_t depth_h, int32_t depth_w,
+                          const uint16_t *depth_raw, int32_t depth_h, int32_t depth_w, int32_t depth_tiled,
                           const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
                           const void *maskbits, const uint8_t *labels, const uint32_t *segmap, int32_t word_bits,
                           const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
@@ -484,7 +488,8 @@ typedef struct bff_scene {
     const int32_t *unsort;          /* [n_points] position of original point o in the sorted cloud, or NULL */
     const int32_t *perm;            /* [n_points] original index of sorted position s (inverse of unsort), or NULL */
     const int32_t *s1_run_start, *s1_run_end, *s1_row_run_offs;     /* stage-1 run tables or NULL */
-    int32_t height, width, n_frames, n_mviews, word_bits, n_rows, conf_f16, n_label_ids, s1_rows, depth_h, depth_w, pad_;
+    int32_t height, width, n_frames, n_mviews, word_bits, n_rows, conf_f16, n_label_ids, s1_rows, depth_h, depth_w,
+            depth_tiled;            /* depth_raw is in 8 x 8 tiles (bff_depth_tile_u16) */
 } bff_scene;
 
 typedef struct bff_scene_params {
@@ -566,7 +571,7 @@ int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t n_pad, con
  * per line; line_words >= ceil(ceil(depth_h * depth_w / 64) / 32) as well). */
 int bff_diag_sweep_lines_u16(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
                              const double *cam_intr_host, int32_t n_frames, const uint16_t *depth_raw, int32_t depth_h,
-                             int32_t depth_w, const int32_t *depth_index, int32_t height, int32_t width,
+                             int32_t depth_w, int32_t depth_tiled, const int32_t *depth_index, int32_t height, int32_t width,
                              double depth_thresh, const uint32_t *segmap, int32_t word_bits, const int32_t *frame_mask,
                              uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words, uint32_t *label_lines,
                              void *stream);

@@ -544,7 +544,7 @@ def test_overlapped_ingestion_equals_prepare_scene(api):
                       for f, d in raw.depths.items()}
     a, b = prepare_scene(raw, cfg, device=DEV), ingest.prepare_scene_fast(raw, cfg, device=DEV)
     assert a.depth is None and b.depth is None and torch.equal(a.depth_raw, b.depth_raw)      # resident as stored
-    assert tuple(a.depth_raw.shape[1:]) == (cfg.height_2d // 2, cfg.width_2d // 2)
+    assert a.depth_size == b.depth_size == (cfg.height_2d // 2, cfg.width_2d // 2)           # frames in 8 x 8 tiles
     monkey_env = dict(os.environ)
     os.environ["BFF_DEPTH_RESIZE_PASS"] = "1"                # the separate scale + resize pass: float32 (H, W) images
     try:
@@ -633,9 +633,15 @@ def test_sweep_resizes_raw_depth_per_point(api, case):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         exp, dbg = pref.project_scene_ref(host, cfg, return_debug=True)
-    ds_raw = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=True)
+    ds_raw = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=True)            # 8 x 8-texel tiles (default)
+    os.environ["BFF_DEPTH_TILES"] = "0"
+    try:
+        ds_lin = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=True)        # row-major frames, as stored
+    finally:
+        del os.environ["BFF_DEPTH_TILES"]
     ds_two = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=False)
-    assert ds_raw.depth is None and ds_raw.depth_raw is not None and ds_two.depth_raw is None
+    assert ds_raw.depth is None and ds_raw.depth_size is not None and ds_lin.depth_size is None and ds_two.depth_raw is None
+    c = projection.run_projection(ds_lin, cfg, debug_out=True)
     from beyond_fixed_forms_amd.scene import viewed_frame_ids
     slots = list(dict.fromkeys([fr["frame_id"][:-4] for fr in raw.mask_2d] + viewed_frame_ids(raw.color_files, cfg.downsample_ratio)))
     host_depth = torch.from_numpy(np.stack([host.depths[f].reshape(-1) for f in slots]))
@@ -643,7 +649,7 @@ def test_sweep_resizes_raw_depth_per_point(api, case):
     a = projection.run_projection(ds_raw, cfg, debug_out=True)
     b = projection.run_projection(ds_two, cfg, debug_out=True)
     for k in ("raw_rows", "masked_counts_raw", "viewed_counts"):
-        assert torch.equal(a.debug[k], b.debug[k]), k
+        assert torch.equal(a.debug[k], b.debug[k]) and torch.equal(c.debug[k], b.debug[k]), k
     n = scene.points.shape[0]
     rawbits = np.unpackbits(a.debug["raw_rows"].cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[:, :n].astype(bool)
     assert np.array_equal(rawbits, dbg["raw_ins"].numpy())
