@@ -56,16 +56,16 @@ SIGNATURES = {
     "bff_cosine_rows": [_P, _I, _P, _I, _I, _I, _P, _P],
     "bff_normalized_gemm_f16": [_P, _I, _P, _I, _I, _P, _P],
     "bff_description_means": [_P, _P, _I, _I, _I, _P, _P],
-    "bff_group_components": [_P, _P, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "bff_group_components": [_P, _P, _P, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "bff_or_reduce_grouped": [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],
-    "bff_resolve_overlaps_dev": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P],
+    "bff_resolve_overlaps_dev": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "bff_clear_flagged_chunks_unless": [_P, _I, _L, _P, _P, _P],
     "bff_scene_project": [_P, _P, _P, _P],
     "bff_diag_gather": [_P, _L, _L, _P, _P],
     "bff_diag_sweep_lines": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _I, _P, _P, _P, _L, _P, _P],
     "bff_diag_sweep_lines_u16": [_P, _L, _L, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _D, _P, _I, _P, _P, _P, _L, _P, _P],
     "bff_scatter_bits": [_P, _I, _L, _P, _L, _L, _P, _P, _P],
-    "bff_cross_popcount_dev": [_P, _I, _P, _I, _L, _P, _P, _I, _I, _P],
+    "bff_cross_popcount_dev": [_P, _I, _P, _I, _L, _P, _P, _I, _I, _P, _P],
     "bff_cloud_layout": [_P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "bff_sort_f32": [_P, _P, _L, _P, _P, _P],
     "bff_argsort_i64": [_P, _P, _P, _I, _I, _P, _P, _P],
@@ -75,7 +75,7 @@ PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, [
          "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_label_plane_stride": (c_int64, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
          "bff_point_tile_size": (c_int32, []), "bff_depth_tiled_texels": (c_int64, [c_int32, c_int32]), "bff_merge_scratch_words": (c_int64, [c_int32]), "bff_merge_uses_chunk_bound": (c_int32, [c_int64]),
          "bff_profile_next_merge": (c_int32, [_P, _P]), "bff_group_slice_cap": (c_int32, [c_int32, c_int32]),
-         "bff_resolve_overlaps_scratch_words": (c_int64, []), "bff_point_threshold_scratch_words": (c_int64, []), "bff_scene_header_words": (c_int32, [c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
+         "bff_resolve_overlaps_scratch_words": (c_int64, []), "bff_point_threshold_scratch_words": (c_int64, [c_int64]), "bff_point_threshold_capacity": (c_int32, []), "bff_point_threshold_capacity_set": (c_int32, [c_int32]), "bff_scene_header_words": (c_int32, [c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
          "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
          "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}
@@ -586,13 +586,13 @@ def point_threshold(masked, viewed, fraction):
 
 
 def point_threshold_pairs(masked, viewed, fraction):
-    """point_threshold without sorting: the statistic is a function of the integer pair (masked, viewed); mark the
-    pairs that occur, hash their float32 values into a set, radix-select the rank.  Returns (thr f32[1], n_unique
-    i32[1], overflow i32[1]) on the device; overflow != 0: more distinct values than the set holds (2^17), use
-    point_threshold."""
+    """point_threshold without sorting: the statistic is a function of the integer pair (masked, viewed); every block
+    lists the distinct float32 values of its points, one block merges the lists in an LDS set and radix-selects the
+    rank.  Returns (thr f32[1], n_unique i32[1], overflow i32[1]) on the device; overflow != 0: more distinct values
+    than the set holds (bff_point_threshold_capacity()), use point_threshold."""
     n = masked.shape[0]
     dev = masked.device
-    scratch = torch.empty(int(load().bff_point_threshold_scratch_words()), dtype=i32, device=dev)
+    scratch = torch.empty(int(load().bff_point_threshold_scratch_words(n)), dtype=i32, device=dev)
     thr = torch.empty(1, dtype=f32, device=dev)
     n_unique = torch.empty(1, dtype=i32, device=dev)
     overflow = torch.zeros(1, dtype=i32, device=dev)

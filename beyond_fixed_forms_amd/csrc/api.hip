@@ -8,6 +8,10 @@ char *err_buf() {
     static thread_local char buf[512] = {0};
     return buf;
 }
+int &scratch_prezeroed() {
+    static thread_local int flag = 0;
+    return flag;
+}
 }  // namespace bff
 
 extern "C" int bff_abi_version(void) { return BFF_ABI_VERSION; }

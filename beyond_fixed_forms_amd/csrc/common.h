@@ -34,6 +34,14 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// bff_scene_project clears every scratch buffer of its steps with ONE fill (they are laid out in one block,
+// bff_scene_workspace) and sets this flag for the duration of the call: the steps' own clears become no-ops.
+int &scratch_prezeroed();
+inline hipError_t zero_async(void *p, size_t bytes, hipStream_t st)
+{
+    return scratch_prezeroed() ? hipSuccess : hipMemsetAsync(p, 0, bytes, st);
+}
+
 #define BFF_REQUIRE(cond, ...) \
     do { if (!(cond)) return ::bff::fail(BFF_E_ARG, __VA_ARGS__); } while (0)
 #define BFF_LIMIT(cond, ...) \

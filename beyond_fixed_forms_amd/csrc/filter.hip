@@ -93,49 +93,33 @@ __global__ __launch_bounds__(1024) void distinct_select_kernel(const float *__re
 // The filter statistic of a point is a function of two small integers, (masked, viewed): float32(masked) /
 // (float32(viewed) + 1) (or float32(masked) alone).  A scene has ~10^5..10^6 points but only ~10^3..10^4 distinct
 // values, so: (1) every block of 1024 points collects the distinct values of ITS points in an LDS hash set (most
-// points repeat a value -- half of them are 0 -- and LDS reads are coherent, so a repeated value costs one probe),
-// then adds them to a global hash set of bit patterns with compare-and-swap: the set of distinct values is exactly
-// x.unique() of the reference; (2) one block selects the value of rank floor(frac * n_distinct) among them with a
-// 4-pass byte-wise radix select (values are >= 0, so the order of the bit patterns is the order of the values).
-// Two small launches instead of a 9-launch radix sort of N floats; bit-identical threshold.
-constexpr uint32_t kHashSlots = 1u << 18;                     // slots of the global set: it holds 2^17 distinct values
+// points repeat a value -- half of them are 0 -- and a repeated value costs one probe) and writes them to its own
+// slice of a scratch table: no global atomics, nothing to clear; (2) ONE block merges the slices in an LDS hash set
+// of 32 Ki slots -- the set of distinct values is exactly x.unique() of the reference -- counts them and selects the
+// value of rank floor(frac * n_distinct) with a 4-pass byte-wise radix select over the slots (values are >= 0, so the
+// order of the bit patterns is the order of the values).  Two launches instead of the 12 of the sorting path
+// (value pass, 9-launch radix sort, two selection passes); bit-identical threshold.  More distinct values than the set
+// holds: *overflow = 1 and the caller sorts.
 constexpr uint32_t kLocalSlots = 2048;                        // LDS set of one block (1024 points -> <= 1024 values)
 constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;                  // not a value: a NaN pattern (the statistic is never NaN)
+constexpr uint32_t kSetSlots = 1u << 15;                      // the merging block's set: 128 KiB of LDS
+constexpr uint32_t kSetMax = kSetSlots / 4 * 3;               // distinct values it accepts (load factor 3/4)
+constexpr int kSliceWords = 1025;                             // per block: count, then <= 1024 values
 
 __device__ __forceinline__ float pair_value(int m, int v, bool ratio)
 {
     return ratio ? __fdiv_rn((float)m, __fadd_rn((float)v, 1.0f)) : (float)m;
 }
 
-// returns false when the set is full: it holds kHashSlots / 2 values (load factor 1/2 keeps the probe sequences short)
-__device__ __forceinline__ bool hash_insert(uint32_t *__restrict__ table, uint32_t *__restrict__ list,
-                                            uint32_t *__restrict__ count, uint32_t bits)
-{
-    uint32_t h = (bits * 2654435761u) >> (32 - 18);
-    for (uint32_t probe = 0; probe < 4096; ++probe) {
-        uint32_t old = __hip_atomic_load(table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not a stale L1 line
-        if (old == kHashEmpty) {
-            if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kHashSlots / 2) return false;
-            old = atomicCAS(table + h, kHashEmpty, bits);
-        }
-        if (old == kHashEmpty) {
-            const uint32_t at = atomicAdd(count, 1u);
-            if (at < kHashSlots) list[at] = bits;
-            return at < kHashSlots / 2;
-        }
-        if (old == bits) return true;
-        h = (h + 1) & (kHashSlots - 1);
-    }
-    return false;
-}
-
-__global__ __launch_bounds__(1024) void value_set_kernel(const int32_t *__restrict__ masked, const int32_t *__restrict__ viewed,
-                                                          int64_t n, uint32_t *__restrict__ table, uint32_t *__restrict__ list,
-                                                          uint32_t *__restrict__ count, int32_t *__restrict__ overflow)
+__global__ __launch_bounds__(1024) void block_value_sets_kernel(const int32_t *__restrict__ masked,
+                                                                 const int32_t *__restrict__ viewed, int64_t n,
+                                                                 uint32_t *__restrict__ slices)
 {
     __shared__ uint32_t local[kLocalSlots];
+    __shared__ uint32_t s_n;
     const int tid = threadIdx.x;
     for (int q = tid; q < (int)kLocalSlots; q += 1024) local[q] = kHashEmpty;
+    if (tid == 0) s_n = 0;
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
     if (i < n) {
@@ -149,21 +133,55 @@ __global__ __launch_bounds__(1024) void value_set_kernel(const int32_t *__restri
         }
     }
     __syncthreads();
+    uint32_t *out = slices + (int64_t)blockIdx.x * kSliceWords;
     for (int q = tid; q < (int)kLocalSlots; q += 1024) {
         const uint32_t bits = local[q];
-        if (bits != kHashEmpty && !hash_insert(table, list, count, bits)) *overflow = 1;
+        const uint64_t bal = __ballot(bits != kHashEmpty);
+        uint32_t base = 0;
+        if (lane_id() == 0 && bal) base = atomicAdd(&s_n, (uint32_t)__popcll(bal));
+        base = __shfl(base, 0);
+        if (bits != kHashEmpty) out[1 + base + __popcll(bal & ((1ull << lane_id()) - 1))] = bits;
     }
+    __syncthreads();
+    if (tid == 0) out[0] = s_n;
 }
 
-// one block: rank r = floor(frac * n) among the n distinct bit patterns in list[] (all >= 0 as floats), by four
-// 8-bit radix-select passes, most significant byte first
-__global__ __launch_bounds__(1024) void pair_select_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count,
-                                                            double frac, float *__restrict__ thr, int32_t *__restrict__ n_unique)
+__global__ __launch_bounds__(1024) void merge_select_kernel(const uint32_t *__restrict__ slices, int n_slices, double frac,
+                                                             float *__restrict__ thr, int32_t *__restrict__ n_unique,
+                                                             int32_t *__restrict__ overflow, uint32_t set_max)
 {
+    extern __shared__ uint32_t set[];                          // kSetSlots
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_prefix, s_rank;
-    const uint32_t n = min(*count, kHashSlots);
-    const int tid = threadIdx.x;
+    __shared__ uint32_t s_count, s_prefix, s_rank, s_full;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t q = tid; q < kSetSlots; q += 1024) set[q] = kHashEmpty;
+    if (tid == 0) { s_count = 0; s_full = 0; }
+    __syncthreads();
+    // wave w merges slices w, w + 16, ...; lanes stride over a slice's values
+    for (int b = wave; b < n_slices; b += 16) {
+        const uint32_t *sl = slices + (int64_t)b * kSliceWords;
+        const uint32_t cnt = sl[0];
+        for (uint32_t k = lane; k < cnt; k += kWave) {
+            const uint32_t bits = sl[1 + k];
+            uint32_t h = (bits * 2654435761u) >> (32 - 15);
+            for (uint32_t probe = 0; probe < kSetSlots; ++probe) {
+                uint32_t old = set[h];
+                if (old == kHashEmpty) {
+                    if (*(volatile uint32_t *)&s_count >= set_max) { s_full = 1; break; }     // up to 1024 inserts may slip past: the set has room
+                    old = atomicCAS(&set[h], kHashEmpty, bits);
+                    if (old == kHashEmpty) { atomicAdd(&s_count, 1u); break; }
+                }
+                if (old == bits) break;
+                h = (h + 1) & (kSetSlots - 1);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = s_count;
+    if (s_full || n > set_max) {                               // block-uniform
+        if (tid == 0) { *overflow = 1; *n_unique = (int32_t)n; *thr = __builtin_nanf(""); }
+        return;
+    }
     if (tid == 0) {
         *n_unique = (int32_t)n;
         const long long r = (long long)floor(frac * (double)n);
@@ -176,9 +194,9 @@ __global__ __launch_bounds__(1024) void pair_select_kernel(const uint32_t *__res
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const uint32_t prefix = s_prefix, mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (uint32_t i = tid; i < n; i += 1024) {
-            const uint32_t v = list[i];
-            if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+        for (uint32_t q = tid; q < kSetSlots; q += 1024) {
+            const uint32_t v = set[q];
+            if (v != kHashEmpty && (v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
         }
         __syncthreads();
         if (tid == 0) {
@@ -299,25 +317,43 @@ extern "C" int bff_depth_from_u16(const uint16_t *src, int32_t n_frames, int32_t
     return launched("bff_depth_from_u16");
 }
 
-extern "C" int64_t bff_point_threshold_scratch_words(void) { return 2 * (int64_t)kHashSlots + 4; }
+extern "C" int64_t bff_point_threshold_scratch_words(int64_t n_points)
+{
+    return ceil_div(n_points > 0 ? n_points : 1, 1024) * kSliceWords;
+}
+
+static uint32_t g_set_max = kSetMax;
+extern "C" int32_t bff_point_threshold_capacity(void) { return (int32_t)g_set_max; }
+// test hook: a smaller capacity makes ordinary scenes exercise the overflow -> sorting fallback; 0 restores the default
+extern "C" int32_t bff_point_threshold_capacity_set(int32_t cap)
+{
+    g_set_max = (cap > 0 && (uint32_t)cap < kSetMax) ? (uint32_t)cap : kSetMax;
+    return (int32_t)g_set_max;
+}
 
 // thr / n_unique as bff_point_values + bff_sort_f32 + bff_select_unique_rank deliver them, from the distinct values
-// that occur.  scratch: uint32 [bff_point_threshold_scratch_words()].  *overflow (device int32, NOT cleared here) is
-// set to 1 when the scene has more distinct values than the set holds (2^17): thr is then undefined and the caller
-// must take the sorting path.
+// that occur.  scratch: uint32 [bff_point_threshold_scratch_words(n_points)], needs no clearing.  *overflow (device
+// int32, NOT cleared here) is set to 1 when the scene has more distinct values than the merging set holds
+// (bff_point_threshold_capacity()): thr is then undefined and the caller must take the sorting path.
 extern "C" int bff_point_threshold_pairs(const int32_t *masked, const int32_t *viewed, int64_t n_points, double fraction,
                                          uint32_t *scratch, float *thr, int32_t *n_unique, int32_t *overflow, void *stream)
 {
     BFF_REQUIRE(n_points >= 0 && scratch && thr && n_unique && overflow, "bff_point_threshold_pairs: bad arguments");
     hipStream_t st = as_stream(stream);
-    uint32_t *table = scratch, *list = table + kHashSlots, *count = list + kHashSlots;
-    hipError_t e = hipMemsetAsync(table, 0xFF, sizeof(uint32_t) * kHashSlots, st);
-    if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(uint32_t) * 4, st);
-    if (e != hipSuccess) return fail((int)e, "bff_point_threshold_pairs: memset: %s", hipGetErrorString(e));
+    const int64_t n_slices = n_points > 0 ? ceil_div(n_points, 1024) : 0;
+    BFF_LIMIT(n_slices < (1ll << 30), "bff_point_threshold_pairs: too many points");
+    static bool lds_enabled = false;
+    if (!lds_enabled) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(merge_select_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * kSetSlots));
+        if (e != hipSuccess) return fail((int)e, "bff_point_threshold_pairs: LDS attribute: %s", hipGetErrorString(e));
+        lds_enabled = true;
+    }
     if (n_points > 0) {
         BFF_REQUIRE(masked, "bff_point_threshold_pairs: null pointer");
-        value_set_kernel<<<(unsigned)ceil_div(n_points, 1024), 1024, 0, st>>>(masked, viewed, n_points, table, list, count, overflow);
+        block_value_sets_kernel<<<(unsigned)n_slices, 1024, 0, st>>>(masked, viewed, n_points, scratch);
     }
-    pair_select_kernel<<<1, 1024, 0, st>>>(list, count, fraction, thr, n_unique);
+    merge_select_kernel<<<1, 1024, sizeof(uint32_t) * kSetSlots, st>>>(scratch, (int)n_slices, fraction, thr, n_unique, overflow,
+                                                                       g_set_max);
     return launched("bff_point_threshold_pairs");
 }

@@ -716,8 +716,7 @@ static int rle_decode(const int32_t *run_start, const int32_t *run_end, const in
     const int64_t seg_words = ceil_div(ceil_div(n_pixels, 128), 32);
     BFF_REQUIRE(!labels || segmap, "bff_rle_to_labels: the label plane needs its segment bitmap");
     if (segmap) {
-        hipError_t e = hipMemsetAsync(segmap, 0, sizeof(uint32_t) * (size_t)n_views * seg_words * (labels ? 2 : 1),
-                                      as_stream(stream));
+        hipError_t e = zero_async(segmap, sizeof(uint32_t) * (size_t)n_views * seg_words * (labels ? 2 : 1), as_stream(stream));
         if (e != hipSuccess) return fail((int)e, "bff_rle_to_maskbits: memset: %s", hipGetErrorString(e));
     }
     const int64_t ls = bff_label_plane_stride(n_pixels);

@@ -83,12 +83,16 @@ __device__ __forceinline__ void tile_popcount(const uint64_t *__restrict__ a, co
     }
 }
 
+constexpr int kFuseMax = 256;     // rows of the fused overlap pass = groups the device forms by itself
+constexpr int kMW = kFuseMax / 64; // words of one row's pair mask
+
 __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__restrict__ a,
                                                               const int32_t *__restrict__ ia, int na,
                                                               const uint64_t *__restrict__ b,
                                                               const int32_t *__restrict__ ib, int nb, int64_t nw,
                                                               int64_t k_split, int32_t *__restrict__ inter,
-                                                              const int32_t *__restrict__ k_dev, int lim_a, int hole_hi)
+                                                              const int32_t *__restrict__ k_dev, int lim_a, int hole_hi,
+                                                              unsigned long long *__restrict__ pmask)
 {
     // k_dev (optional): only the first *k_dev rows of a (when lim_a) resp. of b's leading block [0, hole_hi) hold data,
     // the rest of those ranges is all zero: tiles that lie entirely in the zero part are skipped (the output is
@@ -117,6 +121,26 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
                 else if (acc[r][c]) atomicAdd(inter + (int64_t)i * nb + j, acc[r][c]);
             }
         }
+    if (pmask) {
+        // pair flags of solve_overlapping (P:289-292), a == b: pmask[i] bit j = rows j > i that overlap row i.  The words
+        // of a block are a partial intersection; a pair overlaps iff some part of it does, so the parts' flags are OR-ed
+        // into the zeroed mask (kMW words per row).  Thread (ti, tj) holds the flags of a 4 x 4 patch: row i's 64
+        // columns of this tile meet in LDS.
+        __shared__ uint8_t flag[kT][kT + 4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = i0 + ti * 4 + r, j = j0 + tj * 4 + c;
+                flag[ti * 4 + r][tj * 4 + c] = (i < na && j < nb && j > i && acc[r][c] > 0) ? 1 : 0;
+            }
+        __syncthreads();
+        if (threadIdx.x < kT && i0 + (int)threadIdx.x < na && (int)blockIdx.x < kMW && i0 + (int)threadIdx.x < kFuseMax) {
+            unsigned long long w = 0;
+            for (int c = 0; c < kT; ++c) w |= (unsigned long long)flag[threadIdx.x][c] << c;
+            if (w) atomicOr(pmask + (int64_t)(i0 + threadIdx.x) * kMW + blockIdx.x, w);
+        }
+    }
 }
 
 // ---- row statistics for the block-sparse Gram -------------------------------------------------
@@ -283,13 +307,14 @@ __global__ __launch_bounds__(256) void tile_masks_kernel(const uint64_t *__restr
                                                           uint32_t *__restrict__ tile_hmax, int32_t *__restrict__ tile_amin,
                                                           const int32_t *__restrict__ label_id,
                                                           int32_t *__restrict__ row_sorted, int32_t *__restrict__ area_sorted,
-                                                          int32_t *__restrict__ label_sorted)
+                                                          int32_t *__restrict__ label_sorted, int32_t *__restrict__ parent_init)
 {
     __shared__ uint32_t s_hmax[kBins];
     __shared__ int s_amin;
     const int t = blockIdx.x, tid = threadIdx.x, k = tid & 63, q = tid >> 6;
     const int pos = t * kT + k;
     const int row = pos < n ? (order ? order[pos] : pos) : -1;
+    if (parent_init && q == 0 && row >= 0) parent_init[row] = row;     // disjoint-set forest: every row its own root
     // chunk-mask OR: lanes = rows, each wave takes every 4th mask word and OR-reduces it across the wave
     for (int i = q; i < mw; i += 4) {
         uint64_t v = row >= 0 ? cmask[(int64_t)row * mw + i] : 0;
@@ -1281,7 +1306,6 @@ __global__ void permute_bits_kernel(const uint64_t *__restrict__ in, int64_t nw_
 
 // ---- group OR / confidence mean ---------------------------------------------------------------
 constexpr int kOrSplit = 32;      // members per block along z
-constexpr int kFuseMax = 256;     // rows of the fused overlap pass = groups the device forms by itself
 
 // Sequential mean of one group's confidences by the first wave of the calling block: all its lanes gather
 // 1024 confidences into LDS at once (the gathers are the slow part), then lane 0 runs the strictly sequential
@@ -1373,12 +1397,18 @@ __global__ __launch_bounds__(64) void group_conf_mean_kernel(const T *__restrict
 //   info[0] = K (number of kept groups, may exceed cap), info[1] = flags (1: K > cap, 2: empty components survive
 //   the filter, i.e. min_members <= 0 -- both mean "take the general host path"), info[2] = largest kept group,
 //   info[3] = number of 32-member slices of the kept groups (work items of bff_or_reduce_grouped).
-__global__ void group_count_kernel(const int32_t *__restrict__ comp, int n, int32_t *__restrict__ count)
+__global__ void group_count_kernel(int32_t *__restrict__ comp, int n, int32_t *__restrict__ count,
+                                   int32_t *__restrict__ parent)
 {
     // 64 consecutive rows (two views' masks) belong to a handful of components: one atomic per distinct root of the
-    // wave instead of one per row (thousands of rows share a few dozen counters)
+    // wave instead of one per row (thousands of rows share a few dozen counters).  parent != NULL: comp is an OUTPUT,
+    // the flattened disjoint-set forest (comp[i] = root of i = smallest row of its component; uf_flatten_kernel fused).
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int root = i < n ? comp[i] : -1;
+    int root = -1;
+    if (i < n) {
+        if (parent) { root = uf_find(parent, i); comp[i] = root; }
+        else root = comp[i];
+    }
     uint64_t todo = __ballot(root >= 0);
     while (todo) {
         const int leader = __ffsll((unsigned long long)todo) - 1;
@@ -1645,8 +1675,6 @@ __global__ void apply_row_ops_kernel(uint64_t *__restrict__ rows, int64_t nw, co
 
 // Pair flags of solve_overlapping (P:289-292) from the intersections BEFORE any edit: pmask[i] = bit set over the
 // rows j > i that overlap row i (kFuseMax / 64 words per row), before[i] = |row i| (P:592).  One wave per row.
-constexpr int kMW = kFuseMax / 64;
-
 __global__ __launch_bounds__(256) void overlap_masks_kernel(const int32_t *__restrict__ inter, int stride, int k,
                                                              const int32_t *__restrict__ k_dev,
                                                              unsigned long long *__restrict__ pmask,
@@ -1675,7 +1703,9 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
                                                               const int32_t *__restrict__ size,
                                                               const uint64_t *__restrict__ keep,
                                                               int32_t *__restrict__ after,
-                                                              const int32_t *__restrict__ k_dev)
+                                                              const int32_t *__restrict__ k_dev,
+                                                              const int32_t *__restrict__ inter, int stride,
+                                                              int32_t *__restrict__ before)
 {
     // k_dev != NULL: the row count lives on the device (groups formed there); k is then the capacity the launch
     // was sized for and a count beyond it leaves the rows alone (the host sees the count and takes the general path)
@@ -1684,6 +1714,10 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
         if (kd <= 0 || kd > k) return;
         k = kd;
     }
+    // before[i] = |row i| (P:592) = the diagonal of the intersections taken before any edit (when the pair masks came
+    // out of bff_cross_popcount_dev's epilogue instead of overlap_masks_kernel, which writes them too)
+    if (before && blockIdx.x == 0)
+        for (int r = threadIdx.x; r < k; r += kWave) before[r] = inter[(int64_t)r * stride + r];
     constexpr int kPitch = kWave + 1;                        // column- and row-wise LDS accesses both conflict-free
     __shared__ unsigned long long s_mask[kFuseMax * kMW];    // row i -> rows j > i that overlap it
     __shared__ int s_size[kFuseMax];
@@ -1939,18 +1973,20 @@ extern "C" int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t 
         if (e != hipSuccess) return fail((int)e, "bff_cross_popcount: memset: %s", hipGetErrorString(e));
     }
     dim3 grid((unsigned)ceil_div(nb, kT), (unsigned)ceil_div(na, kT), (unsigned)nz);
-    cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, ia, na, b, ib, nb, nw, k_split, inter, nullptr, 0, 0);
+    cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, ia, na, b, ib, nb, nw, k_split, inter, nullptr, 0, 0, nullptr);
     return launched("bff_cross_popcount");
 }
 
 // bff_cross_popcount where only the first *k_dev rows of the leading `lead` rows of b (and, with limit_a != 0, of a)
 // are non-zero: tiles inside the zero part are skipped.  inter is zeroed first.
 extern "C" int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint64_t *b, int32_t nb, int64_t nw,
-                                      int32_t *inter, const int32_t *k_dev, int32_t limit_a, int32_t lead, void *stream)
+                                      int32_t *inter, const int32_t *k_dev, int32_t limit_a, int32_t lead,
+                                      uint64_t *pair_masks, void *stream)
 {
     BFF_REQUIRE(na >= 0 && nb >= 0 && nw >= 0 && lead >= 0 && lead <= nb, "bff_cross_popcount_dev: bad sizes");
     if (na == 0 || nb == 0) return BFF_OK;
     BFF_REQUIRE(a && b && inter && k_dev, "bff_cross_popcount_dev: null pointer");
+    BFF_REQUIRE(!pair_masks || (a == b && na == nb && na <= kFuseMax), "bff_cross_popcount_dev: pair masks need a == b, <= %d rows", kFuseMax);
     const int64_t tiles = ceil_div(nb, kT) * ceil_div(na, kT);
     int64_t k_split = nw;
     if (tiles < 512) {
@@ -1958,11 +1994,12 @@ extern "C" int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint6
         if (k_split < 2 * kKW) k_split = 2 * kKW;
     }
     const int64_t nz = ceil_div(nw, k_split);
-    hipError_t e = hipMemsetAsync(inter, 0, sizeof(int32_t) * (size_t)na * nb, as_stream(stream));
+    hipError_t e = zero_async(inter, sizeof(int32_t) * (size_t)na * nb, as_stream(stream));
+    if (e == hipSuccess && pair_masks) e = zero_async(pair_masks, sizeof(uint64_t) * (size_t)kFuseMax * kMW, as_stream(stream));
     if (e != hipSuccess) return fail((int)e, "bff_cross_popcount_dev: memset: %s", hipGetErrorString(e));
     dim3 grid((unsigned)ceil_div(nb, kT), (unsigned)ceil_div(na, kT), (unsigned)(nz > 0 ? nz : 1));
     cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, nullptr, na, b, nullptr, nb, nw, k_split, inter, k_dev,
-                                                              limit_a, lead);
+                                                              limit_a, lead, (unsigned long long *)pair_masks);
     return launched("bff_cross_popcount_dev");
 }
 
@@ -1979,7 +2016,7 @@ extern "C" int bff_row_stats(const uint64_t *rows, int32_t n_rows, int64_t nw, i
     static_assert(kBins == kWave, "row_stats_sparse_kernel: one histogram bin per lane");
     if (chunk_mask_given) {
         if (chunk_pop) {                            // the sparse pass writes the flagged chunks only
-            hipError_t e = hipMemsetAsync(chunk_pop, 0, sizeof(uint16_t) * (size_t)n_rows * mw * 64, as_stream(stream));
+            hipError_t e = zero_async(chunk_pop, sizeof(uint16_t) * (size_t)n_rows * mw * 64, as_stream(stream));
             if (e != hipSuccess) return fail((int)e, "bff_row_stats: memset: %s", hipGetErrorString(e));
         }
         row_stats_sparse_kernel<<<(unsigned)ceil_div(n_rows, 4), 256, 0, as_stream(stream)>>>(
@@ -2033,7 +2070,7 @@ extern "C" int bff_merge_adjacency(const uint64_t *rows, int32_t n_rows, int64_t
     // pairs with an empty intersection have IoU 0 (or NaN): they can only be skipped when 0 > thr is false
     const bool sparse = chunk_mask && !(0.0f > iou_thres);
     if (sparse) tile_masks_kernel<<<nt, 256, 0, as_stream(stream)>>>(chunk_mask, order, n_rows, mw, tile_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
-                                                                     nullptr, nullptr, nullptr, nullptr);
+                                                                     nullptr, nullptr, nullptr, nullptr, nullptr);
     const int aw = nt;   // ceil(n_rows/64) words per adjacency row
     merge_adjacency_kernel<<<(unsigned)((int64_t)nt * (nt + 1) / 2), 256, 0, as_stream(stream)>>>(
         rows, n_rows, nw, order, sparse ? tile_mask : nullptr, mw, (sparse && !inter) ? hist : nullptr, area, label_id,
@@ -2085,7 +2122,9 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
     const int mw = (int)ceil_div(n_chunks, 64);
     hipStream_t st = as_stream(stream);
     if (chunk_pop && !bff_merge_uses_chunk_bound(nw)) chunk_pop = nullptr;
-    if (init_parent) uf_init_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows);
+    // every row appears once in `order` when it lists all of them: the tile pre-pass initialises the forest on the way
+    const bool init_in_tiles = init_parent && n_order == n_rows && n_order > 0;
+    if (init_parent && !init_in_tiles) uf_init_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows);
     if (n_order > 0) {
         // an empty intersection gives IoU 0 (or NaN): such pairs can only be skipped when 0 > thr is false
         const bool sparse = !(0.0f > iou_thres);
@@ -2112,7 +2151,8 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
         static const bool split_on = [] { const char *e = getenv("BFF_MERGE_SPLIT"); return !e || atoi(e) != 0; }();
         const bool do_split = split_on && sparse;
         tile_masks_kernel<<<nt, 256, 0, st>>>(chunk_mask, order, n_order, mw, tile_mask, hist, hist_sorted, (int)n_pos, area,
-                                             tile_hmax, tile_amin, label_id, row_sorted, area_sorted, label_sorted);
+                                             tile_hmax, tile_amin, label_id, row_sorted, area_sorted, label_sorted,
+                                             init_in_tiles ? parent : nullptr);
         // Pre-pass over pairs 1, 2, 3, 5 apart in the tile order: it used to shorten the tile pass when every proven
         // edge went into the global forest at once; with local sets and early settling inside the tiles it no
         // longer pays (config 2, 4 rotating scenes: 754 scenes/s with 4 strides, 768 without) -> off unless asked for.
@@ -2126,8 +2166,8 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
             uf_skeleton_kernel<<<sgrid, 256, 0, st>>>(rows, n_order, nw, order, chunk_mask, mw, area, label_id, iou_thres,
                                                       parent, kStrides);
         }
-        hipError_t e = hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), st);
-        if (e == hipSuccess && do_split) e = hipMemsetAsync(arrive, 0, sizeof(int32_t) * (size_t)kMaxSlots * (kT * kT + 1), st);
+        hipError_t e = zero_async(counts, 4 * sizeof(int32_t), st);
+        if (e == hipSuccess && do_split) e = zero_async(arrive, sizeof(int32_t) * (size_t)kMaxSlots * (kT * kT + 1), st);
         if (e != hipSuccess) return fail((int)e, "bff_merge_components: memset: %s", hipGetErrorString(e));
         tile_pair_filter_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(tile_hmax, tile_amin, nt, (int)total,
                                                                                iou_thres, list1, counts);
@@ -2253,24 +2293,27 @@ extern "C" int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const
                                                                                 (unsigned long long *)pair_masks, before);
     BFF_TRY_LDS(sizeof(uint64_t) * (size_t)k * (kWave + 1), "bff_resolve_overlaps");
     resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave, sizeof(uint64_t) * (size_t)k * (kWave + 1),
-                              as_stream(stream)>>>(rows, nw, k, (const unsigned long long *)pair_masks, size, keep, after, nullptr);
+                              as_stream(stream)>>>(rows, nw, k, (const unsigned long long *)pair_masks, size, keep, after, nullptr,
+                                                   nullptr, 0, nullptr);
     return launched("bff_resolve_overlaps");
 }
 
 extern "C" int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *inter,
                                         const int32_t *size, const uint64_t *keep, int32_t *before, int32_t *after,
-                                        uint64_t *pair_masks, const int32_t *k_dev, void *stream)
+                                        uint64_t *pair_masks, int32_t masks_ready, const int32_t *k_dev, void *stream)
 {
     BFF_REQUIRE(k_cap > 0 && nw >= 0, "bff_resolve_overlaps_dev: bad sizes");
     BFF_LIMIT(k_cap <= kFuseMax, "bff_resolve_overlaps_dev: capacity beyond %d rows", kFuseMax);
     BFF_REQUIRE(rows && inter && size && before && after && k_dev && pair_masks, "bff_resolve_overlaps_dev: null pointer");
-    hipError_t e = hipMemsetAsync(after, 0, sizeof(int32_t) * (size_t)k_cap, as_stream(stream));
+    hipError_t e = zero_async(after, sizeof(int32_t) * (size_t)k_cap, as_stream(stream));
     if (e != hipSuccess) return fail((int)e, "bff_resolve_overlaps_dev: memset: %s", hipGetErrorString(e));
-    overlap_masks_kernel<<<(unsigned)ceil_div(k_cap, 4), 256, 0, as_stream(stream)>>>(inter, k_cap, k_cap, k_dev,
-                                                                                    (unsigned long long *)pair_masks, before);
+    if (!masks_ready)           // masks_ready: bff_cross_popcount_dev(..., pair_masks) built them with the intersections
+        overlap_masks_kernel<<<(unsigned)ceil_div(k_cap, 4), 256, 0, as_stream(stream)>>>(inter, k_cap, k_cap, k_dev,
+                                                                                        (unsigned long long *)pair_masks, before);
     BFF_TRY_LDS(sizeof(uint64_t) * (size_t)k_cap * (kWave + 1), "bff_resolve_overlaps_dev");
     resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave, sizeof(uint64_t) * (size_t)k_cap * (kWave + 1),
-                              as_stream(stream)>>>(rows, nw, k_cap, (const unsigned long long *)pair_masks, size, keep, after, k_dev);
+                              as_stream(stream)>>>(rows, nw, k_cap, (const unsigned long long *)pair_masks, size, keep, after, k_dev,
+                                                   inter, k_cap, masks_ready ? before : nullptr);
     return launched("bff_resolve_overlaps_dev");
 }
 
@@ -2373,7 +2416,7 @@ extern "C" int bff_ids_to_rows(const int64_t *ids, int64_t n_points, const int64
 
 extern "C" int32_t bff_group_slice_cap(int32_t n_rows, int32_t cap) { return n_rows / kOrSplit + cap + 1; }
 
-extern "C" int bff_group_components(const int32_t *comp, const int32_t *area, int32_t n_rows, float iou_thres,
+extern "C" int bff_group_components(int32_t *comp, int32_t *parent, const int32_t *area, int32_t n_rows, float iou_thres,
                                     int32_t min_members, int32_t cap, int32_t *count, int32_t count_is_zero,
                                     int32_t *info, int32_t *sizes,
                                     int32_t *first, int32_t *offs, int32_t *members, int32_t *slices, void *stream)
@@ -2388,7 +2431,7 @@ extern "C" int bff_group_components(const int32_t *comp, const int32_t *area, in
             hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t) * (size_t)n_rows, st);
             if (e != hipSuccess) return fail((int)e, "bff_group_components: memset: %s", hipGetErrorString(e));
         }
-        group_count_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(comp, n_rows, count);
+        group_count_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(comp, n_rows, count, parent);
     }
     group_scan_kernel<<<1, 1024, 0, st>>>(comp, count, area, n_rows, iou_thres, min_members, cap, info, sizes, first, offs,
                                          slices, bff_group_slice_cap(n_rows, cap));
@@ -2408,7 +2451,7 @@ extern "C" int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n
                 "bff_or_reduce_grouped: conf and conf_mean go together, dtype 0 (f32) or 1 (f16)");
     hipStream_t st = as_stream(stream);
     if (nw > 0) {
-        hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t) * (size_t)cap * nw, st);
+        hipError_t e = zero_async(out, sizeof(uint64_t) * (size_t)cap * nw, st);
         if (e != hipSuccess) return fail((int)e, "bff_or_reduce_grouped: memset: %s", hipGetErrorString(e));
     }
     const int slice_cap = bff_group_slice_cap(n_rows, cap);

@@ -58,17 +58,38 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
 #define BFF_ZERO(ptr, bytes) do { e = hipMemsetAsync((ptr), 0, (bytes), st); \
         if (e != hipSuccess) return fail((int)e, "bff_scene_project: memset: %s", hipGetErrorString(e)); } while (0)
 
+    // ONE fill clears every scratch buffer of the call: counters, chunk flags, segment bitmap, header, merge lists and
+    // split slots, intersections, pair masks, the OR targets (bff_scene_workspace lays them out in one block); the steps'
+    // own clears are switched off for the duration of the call
+    BFF_REQUIRE(ws->zero_bytes > 0 && ws->masked, "bff_scene_project: no zero block");
+    {
+        const char *z0 = reinterpret_cast<const char *>(ws->masked), *z1 = z0 + ws->zero_bytes;
+        auto inside = [&](const void *p, size_t bytes) {
+            const char *c = reinterpret_cast<const char *>(p);
+            return p != nullptr && c >= z0 && c + bytes <= z1;
+        };
+        const size_t seg_bytes = sizeof(uint32_t) * 2 * (size_t)sc->n_mviews * (size_t)ceil_div(ceil_div(hw, 128), 32);
+        const bool use_cpop = bff_merge_uses_chunk_bound(nw) != 0;
+        BFF_REQUIRE(inside(ws->masked, sizeof(int32_t) * (size_t)n) && inside(ws->viewed, sizeof(int32_t) * (size_t)n) &&
+                    inside(ws->count, sizeof(int32_t) * (size_t)n_rows) &&
+                    inside(ws->chunk_mask, sizeof(uint64_t) * (size_t)n_rows * mw) && inside(ws->segmap, seg_bytes) &&
+                    inside(hdr, sizeof(int32_t) * (size_t)bff_scene_header_words(sc->s1_rows)) &&
+                    inside(ws->inter, sizeof(int32_t) * (size_t)cap * cap) && inside(ws->agg, sizeof(uint64_t) * (size_t)cap * nw) &&
+                    inside(ws->merge_scratch, sizeof(uint32_t) * (size_t)bff_merge_scratch_words(n_rows)) &&
+                    inside(ws->pair_masks, sizeof(uint64_t) * (size_t)bff_resolve_overlaps_scratch_words()) &&
+                    (!use_cpop || inside(ws->chunk_pop, sizeof(uint16_t) * (size_t)n_rows * mw * 64)),
+                    "bff_scene_project: a scratch buffer lies outside the zero block (workspace layout)");
+    }
+    BFF_ZERO(ws->masked, ws->zero_bytes);
+    struct Prezeroed {
+        Prezeroed() { scratch_prezeroed() = 1; }
+        ~Prezeroed() { scratch_prezeroed() = 0; }
+    } prezeroed_scope;
     // a1: 2-D RLE -> label plane (+ words where masks overlap, + segment bitmap)
     BFF_TRY(bff_rle_to_labels(sc->run_start, sc->run_end, sc->mask_run_offs, sc->view_mask_offs, sc->n_mviews, hw,
                               sc->word_bits, ws->labels, ws->maskbits, ws->segmap, stream));
-    // a2-a8 (+a15): the fused sweep.  ws->rows is all zero on entry (and again on exit, see below); the counters,
-    // the group counters and the chunk flags are one block, cleared by one fill
+    // a2-a8 (+a15): the fused sweep.  ws->rows is all zero on entry (and again on exit, see below)
     const bool ratio = pr->filter_mode == 2;
-    BFF_REQUIRE(ws->zero_bytes >= sizeof(int32_t) * (size_t)(2 * n + n_rows) + sizeof(uint64_t) * (size_t)n_rows * mw &&
-                reinterpret_cast<char *>(ws->chunk_mask) + sizeof(uint64_t) * (size_t)n_rows * mw <=
-                reinterpret_cast<char *>(ws->masked) + ws->zero_bytes, "bff_scene_project: zero block too small");
-    BFF_ZERO(ws->masked, ws->zero_bytes);
-    BFF_ZERO(hdr, sizeof(int32_t) * BFF_HDR_SIZES);
     if (sc->depth_raw)          // depth as the PNGs store it: /1000 + bilinear resize per point inside the sweep
         BFF_TRY(bff_project_views_u16(sc->xyz, n, sc->n_pad, sc->inv_pose, sc->cam_intr, sc->n_frames, sc->depth_raw,
                                       sc->depth_h, sc->depth_w, sc->depth_tiled, sc->depth_index, sc->height, sc->width, pr->depth_thresh,
@@ -82,13 +103,13 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
                                   ws->chunk_mask, ws->masked, ratio ? ws->viewed : nullptr, sc->tile_bounds, stream));
     // a14 / a15: point filter, threshold stays on the device (header words 2, 3 = n_unique, thr)
     if (pr->filter_mode != 0) {
-        if (pr->filter_sort) {          // the general formulation: sort all n values (scenes with > 2^18 distinct ones)
+        if (pr->filter_sort) {          // the general formulation: sort all n values (more distinct ones than the set holds)
             BFF_TRY(bff_point_values(ws->masked, ratio ? ws->viewed : nullptr, n, ws->vals, stream));
             size_t tb = ws->sort_temp_bytes;
             BFF_TRY(bff_sort_f32(ws->vals, ws->vals_sorted, n, ws->sort_temp, &tb, stream));
             BFF_TRY(bff_select_unique_rank(ws->vals_sorted, n, pr->filter_fraction, ws->sel_scratch,
                                            reinterpret_cast<float *>(hdr + BFF_HDR_THR), hdr + BFF_HDR_NUNIQUE, stream));
-        } else {                        // the statistic is a function of (masked, viewed): distinct pairs, no sort
+        } else {                        // the statistic is a function of (masked, viewed): distinct values, no sort
             BFF_TRY(bff_point_threshold_pairs(ws->masked, ratio ? ws->viewed : nullptr, n, pr->filter_fraction,
                                               ws->pair_scratch, reinterpret_cast<float *>(hdr + BFF_HDR_THR),
                                               hdr + BFF_HDR_NUNIQUE, hdr + BFF_HDR_OVERFLOW, stream));
@@ -113,24 +134,27 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
         size_t tb = ws->sort_temp_bytes;
         BFF_TRY(bff_argsort_i64(keys, ws->sig_sorted, ws->order, n_rows, key_bits, ws->sort_temp, &tb, stream));
     }
+    // the forest is initialised by the tile pre-pass and flattened by the grouping step (comp == NULL here)
     BFF_TRY(bff_merge_components(ws->rows, n_rows, nw, ws->order, n_rows, ws->chunk_mask, ws->tile_mask, ws->hist,
-                                 ws->merge_scratch, ws->area, sc->label_id, pr->iou_thres, ws->parent, 1, ws->comp, nullptr,
+                                 ws->merge_scratch, ws->area, sc->label_id, pr->iou_thres, ws->parent, 1, nullptr, nullptr,
                                  cpop, stream));
     // P:203-226 on the device: groups, OR of the members, sequential confidence means
     int32_t *info = hdr + BFF_HDR_K;
-    BFF_TRY(bff_group_components(ws->comp, ws->area, n_rows, pr->iou_thres, pr->min_members, cap, ws->count, 1, info,
+    BFF_TRY(bff_group_components(ws->comp, ws->parent, ws->area, n_rows, pr->iou_thres, pr->min_members, cap, ws->count, 1, info,
                                  hdr + BFF_HDR_SIZES, hdr + BFF_HDR_FIRST, ws->goffs, ws->gmembers, ws->slices, stream));
     BFF_TRY(bff_or_reduce_grouped(ws->rows, nw, n_rows, info, cap, ws->goffs, ws->gmembers, ws->slices, ws->agg, sc->conf,
                                   sc->conf_f16, hdr + BFF_HDR_CONF, ws->chunk_mask, stream));
     // last reader of the raw rows is done: give the arena its zeros back -- unless the host has to take the general
     // path (more groups than the device forms), which reads the rows again and clears them itself
     BFF_TRY(bff_clear_flagged_chunks_unless(ws->rows, n_rows, nw, ws->chunk_mask, info + 1, stream));
-    // a16 + P:592-596: intersections before any edit, ordered overlap decisions, &= keep, both popcounts
-    BFF_TRY(bff_cross_popcount_dev(ws->agg, cap, ws->agg, cap, nw, ws->inter, info, 2, cap, stream));
+    // a16 + P:592-596: intersections before any edit (their epilogue leaves the pair flags of P:289-292), ordered
+    // overlap decisions, &= keep, both popcounts
+    BFF_TRY(bff_cross_popcount_dev(ws->agg, cap, ws->agg, cap, nw, ws->inter, info, 2, cap, ws->pair_masks, stream));
     BFF_TRY(bff_resolve_overlaps_dev(ws->agg, cap, nw, ws->inter, hdr + BFF_HDR_SIZES, ws->keep, hdr + BFF_HDR_BEFORE,
-                                     hdr + BFF_HDR_AFTER, ws->pair_masks, info, stream));
+                                     hdr + BFF_HDR_AFTER, ws->pair_masks, 1, info, stream));
     // caller's point order (scatter of the set bits); the refinement's first device pass (R:186-217) rides along when
-    // stage 1 is resident
+    // stage 1 is resident.  `both` is the caller's buffer (it outlives the workspace's reuse): its clear is the one
+    // fill besides the block's
     if (sc->perm) {
         BFF_ZERO(ws->both, sizeof(uint64_t) * (size_t)cap * nw);
         BFF_TRY(bff_scatter_bits(ws->agg, cap, nw, sc->perm, n, nw, ws->both, info, stream));
@@ -142,7 +166,7 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
         uint64_t *s1 = ws->both + (size_t)cap * nw;
         BFF_TRY(bff_rle_to_rows(sc->s1_run_start, sc->s1_run_end, sc->s1_row_run_offs, sc->s1_rows, n, nw, s1, stream));
         BFF_TRY(bff_cross_popcount_dev(s1, sc->s1_rows, ws->both, cap + sc->s1_rows, nw, hdr + BFF_HDR_CROSS, info, 0, cap,
-                                       stream));
+                                       nullptr, stream));
     }
     e = hipMemcpyAsync(ws->hdr_host, hdr, sizeof(int32_t) * (size_t)bff_scene_header_words(sc->s1_rows),
                        hipMemcpyDeviceToHost, st);

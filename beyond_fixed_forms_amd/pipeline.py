@@ -190,39 +190,46 @@ class SceneWorkspace:
         nt = (n_rows + 63) // 64
         i32, i64, f32 = torch.int32, torch.int64, torch.float32
         self._need("maskbits", n_mviews * hw * (1 if ds.word_bits == 32 else 2), i32)
-        self._need("segmap", 2 * n_mviews * _lib.segmap_words(hw), i32)      # two words per 32 segments: occupied | word form
         self._need("labels", n_mviews * int(lib.bff_label_plane_stride(hw)), torch.uint8)
         if self._need("rows", n_rows * nw, i64, zero=True):
             self.rows_dirty = False
-        # masked | viewed | count | chunk_mask: one allocation, cleared by one fill per scene
-        zwords = 2 * n + n_rows + (-(2 * n + n_rows)) % 2                 # int32 words before the 8-byte aligned flags
-        zbytes = 4 * zwords + 8 * n_rows * mw
+        # everything the call's steps expect zeroed lives in ONE allocation, cleared by one fill per scene
+        # (bff_scene_workspace): name -> (bytes, dtype of the view)
+        seg_words = 2 * n_mviews * _lib.segmap_words(hw)
+        hdr_words = int(lib.bff_scene_header_words(s1_rows))
+        use_cpop = bool(lib.bff_merge_uses_chunk_bound(nw))
+        parts = [("masked", 4 * n, i32), ("viewed", 4 * n, i32), ("count", 4 * n_rows, i32),
+                 ("chunk_mask", 8 * n_rows * mw, i64), ("segmap", 4 * seg_words, i32), ("hdr", 4 * hdr_words, i32),
+                 ("inter", 4 * GROUP_CAP * GROUP_CAP, i32), ("pair_masks", 8 * int(lib.bff_resolve_overlaps_scratch_words()), i64),
+                 ("agg", 8 * GROUP_CAP * nw, i64), ("merge_scratch", 4 * int(lib.bff_merge_scratch_words(n_rows)), i32)]
+        if use_cpop:
+            parts.append(("chunk_pop", 2 * n_rows * mw * 64, torch.int16))
+        offs, at = {}, 0
+        for name, nbytes, _dt in parts:
+            offs[name] = at
+            at += (nbytes + 63) // 64 * 64
+        zbytes = max(at, 64)
         if self._need("zero_block", zbytes, torch.uint8):
             pass
         zb = self.t["zero_block"]
-        for name, off in (("masked", 0), ("viewed", 4 * n), ("count", 8 * n), ("chunk_mask", 4 * zwords)):
-            setattr(self.struct, name, c_void_p(zb.data_ptr() + off))
-        self.t["masked"] = zb[0:4 * n].view(i32)
-        self.t["viewed"] = zb[4 * n:8 * n].view(i32)
-        self.t["count"] = zb[8 * n:8 * n + 4 * n_rows].view(i32)
-        self.t["chunk_mask"] = zb[4 * zwords:4 * zwords + 8 * n_rows * mw].view(i64)
+        for name, nbytes, dt in parts:
+            o = offs[name]
+            setattr(self.struct, name, c_void_p(zb.data_ptr() + o))
+            self.t[name] = zb[o:o + nbytes].view(dt)
         self.struct.zero_bytes = zbytes
+        if not use_cpop:
+            self._need("chunk_pop", 1, torch.int16)
         self._need("keep", nw, i64)
         self._need("tile_mask", nt * mw, i64)
-        self._need("agg", GROUP_CAP * nw, i64)
         self._need("sel_scratch", (n + 1023) // 1024, i32)
-        self._need("pair_masks", int(lib.bff_resolve_overlaps_scratch_words()), i64)
-        self._need("pair_scratch", int(lib.bff_point_threshold_scratch_words()), i32)
+        self._need("pair_scratch", int(lib.bff_point_threshold_scratch_words(n)), i32)
         for k in ("area", "mean_word", "order", "parent", "comp", "gmembers"):
             self._need(k, n_rows, i32)
         self._need("goffs", GROUP_CAP + 1, i32)
         self._need("slices", 3 * lib.bff_group_slice_cap(n_rows, GROUP_CAP), i32)
-        self._need("inter", GROUP_CAP * GROUP_CAP, i32)
         self._need("vals", n, f32)
         self._need("vals_sorted", n, f32)
         self._need("hist", n_rows * 64, i32)
-        self._need("chunk_pop", n_rows * mw * 64, torch.int16)
-        self._need("merge_scratch", int(lib.bff_merge_scratch_words(n_rows)), i32)
         for k in ("sig", "sig_keys", "sig_sorted"):
             self._need(k, n_rows, i64)
         # both library sorts share one temp buffer
@@ -233,9 +240,8 @@ class SceneWorkspace:
         nb = max(nb, int(need.value))
         self._need("sort_temp", nb, torch.uint8)
         self.struct.sort_temp_bytes = self.t["sort_temp"].numel()
-        words = int(lib.bff_scene_header_words(s1_rows))
-        if self._need("hdr", words, i32) or self.hdr_host is None or self.hdr_host.numel() < words:
-            self.hdr_host = torch.empty(self.t["hdr"].numel(), dtype=i32, pin_memory=True)
+        if self.hdr_host is None or self.hdr_host.numel() < hdr_words:
+            self.hdr_host = torch.empty(hdr_words, dtype=i32, pin_memory=True)
             self.struct.hdr_host = c_void_p(self.hdr_host.data_ptr())
         return self
 
@@ -269,9 +275,9 @@ def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
         ws.both_primed = n_both
     both = torch.empty((GROUP_CAP + s1_rows, ds.nw), dtype=torch.int64, device=dev)     # outlives the workspace's reuse
     ws.struct.both = c_void_p(both.data_ptr())
-    # the threshold of the point filter: radix sort of all values (default) or the distinct-value set (BFF_FILTER_SET=1;
-    # measured equal at config 2: 86 vs 80 us -- its global hash set serialises on the popular values)
-    use_sort = os.environ.get("BFF_FILTER_SET") != "1" or bool(ds.__dict__.get("_filter_sort", False))
+    # the threshold of the point filter: from the set of distinct values (two launches; default) or by a radix sort of all
+    # values (12 launches; BFF_FILTER_SORT=1, and automatically for a scene with more distinct values than the set holds)
+    use_sort = os.environ.get("BFF_FILTER_SORT") == "1" or bool(ds.__dict__.get("_filter_sort", False))
     pr = params_struct(cfg, depth_thresh, filter_sort=use_sort)
     ws.in_flight = True
     t1 = time.perf_counter() if _TRACE_ISSUE else 0.0

@@ -371,10 +371,13 @@ int bff_ids_to_rows(const int64_t *ids, int64_t n_points, const int64_t *values,
 int bff_point_values(const int32_t *masked, const int32_t *viewed, int64_t n_points, float *vals, void *stream);
 /* The same (thr, n_unique) without sorting n_points values: the statistic is a function of the integer pair (masked,
  * viewed), of which a scene holds only ~10^3..10^4 different ones: every block collects the distinct values of its
- * points in LDS, the blocks' sets meet in a global hash set (= x.unique() of P:516 / P:574), one block radix-selects the
- * rank.  scratch: uint32 [bff_point_threshold_scratch_words()]; *overflow (device, not cleared by the call) is set to 1
- * if the set (2^17 values) is full: use the sorting path then. */
-int64_t bff_point_threshold_scratch_words(void);
+ * 1024 points in LDS and writes them to its slice of `scratch` (no global atomics, nothing to clear), ONE block merges
+ * the slices in an LDS hash set (= x.unique() of P:516 / P:574) and radix-selects the rank: two launches.
+ * scratch: uint32 [bff_point_threshold_scratch_words(n_points)]; *overflow (device, not cleared by the call) is set to 1
+ * if there are more distinct values than bff_point_threshold_capacity(): use the sorting path then. */
+int64_t bff_point_threshold_scratch_words(int64_t n_points);
+int32_t bff_point_threshold_capacity(void);
+int32_t bff_point_threshold_capacity_set(int32_t cap);     /* test hook: smaller capacity (0 = default); returns the new one */
 int bff_point_threshold_pairs(const int32_t *masked, const int32_t *viewed, int64_t n_points, double fraction,
                               uint32_t *scratch, float *thr, int32_t *n_unique, int32_t *overflow, void *stream);
 int bff_select_unique_rank(const float *sorted, int64_t n, double fraction, int32_t *block_scratch,
@@ -440,13 +443,15 @@ int bff_cosine_rows(const void *a, int32_t na, const void *b, int32_t nb, int32_
 #define BFF_SIGNATURE_BITS 30     /* bff_row_stats signatures are 30-bit keys */
 
 /* Device twin of bff_host_component_csr for at most `cap` <= BFF_GROUP_CAP kept groups.  comp[i] = smallest row index
- * of i's component (bff_merge_components).  Outputs (device): info[4] = {K kept groups (may exceed cap), flags (bit 0:
+ * of i's component (bff_merge_components) -- an INPUT when parent == NULL; with parent (the disjoint-set forest
+ * bff_merge_components leaves behind when called with comp == NULL) comp is an OUTPUT, flattened here on the way.
+ * Outputs (device): info[4] = {K kept groups (may exceed cap), flags (bit 0:
  * K > cap, bit 1: min_members <= 0 and empty components exist -- both: use the host path), largest group, number of
  * 32-member slices}; sizes[cap], first[cap] (= smallest member = where the group's label comes from), offs[cap+1],
  * members[n_rows] (ascending inside a group), slices[3 * bff_group_slice_cap(n_rows, cap)] (work items of
  * bff_or_reduce_grouped); count: scratch int32 [n_rows] (count_is_zero != 0: the caller has cleared it). */
 int32_t bff_group_slice_cap(int32_t n_rows, int32_t cap);
-int bff_group_components(const int32_t *comp, const int32_t *area, int32_t n_rows, float iou_thres,
+int bff_group_components(int32_t *comp, int32_t *parent, const int32_t *area, int32_t n_rows, float iou_thres,
                          int32_t min_members, int32_t cap, int32_t *count, int32_t count_is_zero, int32_t *info,
                          int32_t *sizes, int32_t *first, int32_t *offs, int32_t *members, int32_t *slices, void *stream);
 /* bff_or_reduce_groups for those groups: out [cap][nw] (zeroed here; rows >= K stay zero), conf_mean [cap] in the
@@ -455,19 +460,22 @@ int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n_rows, cons
                           const int32_t *offs, const int32_t *members, const int32_t *slices, uint64_t *out,
                           const void *conf, int32_t conf_dtype, void *conf_mean, const uint64_t *chunk_mask, void *stream);
 /* bff_resolve_overlaps with the row count on the device (*k_dev <= k_cap, else nothing is touched); inter is
- * [k_cap][k_cap]. */
+ * [k_cap][k_cap].  masks_ready != 0: pair_masks were built by bff_cross_popcount_dev together with `inter` (one launch
+ * less); `before` is then read off the diagonal of `inter` inside the overlap pass. */
 int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *inter, const int32_t *size,
                              const uint64_t *keep, int32_t *before, int32_t *after, uint64_t *pair_masks,
-                             const int32_t *k_dev, void *stream);
+                             int32_t masks_ready, const int32_t *k_dev, void *stream);
 /* out[r] bit perm[s] = in[r] bit s, set bits only (undoes the spatial point sort by scatter: aggregated rows are
  * sparse); out must be zero; rows >= *k_dev (when given) are skipped. */
 int bff_scatter_bits(const uint64_t *rows_in, int32_t n_rows, int64_t nw_in, const int32_t *perm, int64_t n,
                      int64_t nw_out, uint64_t *rows_out, const int32_t *k_dev, void *stream);
 /* bff_cross_popcount when only the first *k_dev rows of b's leading `lead` rows (and of a, with limit_a) are
  * non-zero: tiles inside the zero part are skipped; inter is zeroed first.  limit_a == 2: a and b are the same rows and
- * only entries inter[i][j] with j >= i (up to tile granularity) are needed. */
+ * only entries inter[i][j] with j >= i (up to tile granularity) are needed.  pair_masks (optional; a == b, at most
+ * BFF_GROUP_CAP rows): also writes the pair flags of solve_overlapping (P:289-292) -- bit j of row i's
+ * BFF_GROUP_CAP / 64 words = rows j > i that overlap row i -- for bff_resolve_overlaps_dev(masks_ready = 1). */
 int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint64_t *b, int32_t nb, int64_t nw, int32_t *inter,
-                           const int32_t *k_dev, int32_t limit_a, int32_t lead, void *stream);
+                           const int32_t *k_dev, int32_t limit_a, int32_t lead, uint64_t *pair_masks, void *stream);
 /* bff_clear_flagged_chunks unless *veto != 0 (device flag). */
 int bff_clear_flagged_chunks_unless(uint64_t *rows, int32_t n_rows, int64_t nw, const uint64_t *chunk_mask,
                                     const int32_t *veto, void *stream);
@@ -503,8 +511,9 @@ typedef struct bff_scene_params {
 
 /* Scratch of bff_scene_project, allocated by the caller for the scene's sizes (beyond_fixed_forms_amd/pipeline.py).
  * `rows` must be all zero on entry; it is all zero again when the call's work has run on the fast path.
- * masked, viewed, count and chunk_mask must be ONE allocation in this order (`zero_bytes` bytes from `masked`): the call
- * clears them with a single fill. */
+ * Every buffer the call's steps expect zeroed -- masked, viewed, count, chunk_mask, segmap, hdr, inter, agg, merge_scratch,
+ * pair_masks and (clouds that use the chunk bound) chunk_pop -- must lie inside ONE allocation of `zero_bytes` bytes
+ * starting at `masked`: the call clears it with a single fill (checked; beyond_fixed_forms_amd/pipeline.py lays it out). */
 typedef struct bff_scene_workspace {
     void *maskbits; uint32_t *segmap;  /* word plane and two-word segment bitmap of bff_rle_to_labels */
     uint8_t *labels;                /* palette blocks, [n_mviews][bff_label_plane_stride(H*W)] */
@@ -512,13 +521,13 @@ typedef struct bff_scene_workspace {
     int32_t *masked, *viewed, *sel_scratch, *area, *mean_word, *order, *parent, *comp, *count;
     int32_t *gmembers, *goffs, *slices, *inter;
     uint64_t *pair_masks;           /* bff_resolve_overlaps_scratch_words() */
-    uint32_t *pair_scratch;         /* bff_point_threshold_scratch_words() */
+    uint32_t *pair_scratch;         /* bff_point_threshold_scratch_words(n_points) */
     float *vals, *vals_sorted;
     uint32_t *hist, *merge_scratch;
     uint16_t *chunk_pop;            /* [n_rows][64 * chunk-mask words] */
     int64_t *sig, *sig_keys, *sig_sorted;
     void *sort_temp; size_t sort_temp_bytes;
-    size_t zero_bytes;              /* size of the block masked | viewed | count | chunk_mask */
+    size_t zero_bytes;              /* size of the block that starts at `masked` (see above) */
     int32_t *hdr;                   /* device, bff_scene_header_words(s1_rows) int32 */
     int32_t *hdr_host;              /* pinned host mirror of the same size */
 } bff_scene_workspace;

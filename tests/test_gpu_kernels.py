@@ -566,13 +566,14 @@ def test_point_filters(lib, mode, n):
 
 
 def test_point_threshold_pairs_out_of_range_and_overflow(lib):
-    """Large counts (thousands of masks / frames per point) and many distinct values; more than 2^17 distinct values
-    set the overflow flag (the caller then sorts)."""
+    """Large counts (thousands of masks / frames per point) and many distinct values; more distinct values than the
+    merging set holds (bff_point_threshold_capacity()) set the overflow flag (the caller then sorts)."""
     import math
     rng = np.random.default_rng(77)
     n = 50_000
-    masked = rng.integers(0, 9000, n)
-    viewed = rng.integers(0, 3000, n)
+    masked = rng.integers(0, 9000, n) // 40 * 40                  # ~20 k distinct ratios: inside the set's capacity
+    viewed = rng.integers(0, 3000, n) // 30 * 30
+    cap = int(lib.load().bff_point_threshold_capacity())
     md = torch.tensor(masked, dtype=torch.int32, device=DEV)
     vd = torch.tensor(viewed, dtype=torch.int32, device=DEV)
     stat = torch.tensor(masked, dtype=torch.float32) / (torch.tensor(viewed, dtype=torch.float32) + 1)
@@ -581,12 +582,15 @@ def test_point_threshold_pairs_out_of_range_and_overflow(lib):
         thr, nu, ovf = lib.point_threshold_pairs(md, vd, f)
         assert int(ovf.item()) == 0 and int(nu.item()) == uniq.shape[0]
         assert thr.cpu().numpy()[0] == uniq[math.floor(f * uniq.shape[0])].numpy()
-    big = torch.arange(300_000, dtype=torch.int32, device=DEV) + 5000          # 300k distinct values, all out of range
+    assert 1000 < uniq.shape[0] <= cap
+    big = torch.arange(cap + 1, dtype=torch.int32, device=DEV) + 5000          # one distinct value too many
     _, _, ovf = lib.point_threshold_pairs(big, None, 0.3)
     assert int(ovf.item()) == 1
-    ok = torch.arange(100_000, dtype=torch.int32, device=DEV) + 5000           # 100k distinct values fit
+    _, _, ovf = lib.point_threshold_pairs(torch.arange(300_000, dtype=torch.int32, device=DEV), None, 0.3)
+    assert int(ovf.item()) == 1
+    ok = torch.arange(cap, dtype=torch.int32, device=DEV) + 5000               # exactly the capacity fits
     thr, nu, ovf = lib.point_threshold_pairs(ok, None, 0.3)
-    assert int(ovf.item()) == 0 and int(nu.item()) == 100_000 and thr.cpu().numpy()[0] == np.float32(5000 + 30_000)
+    assert int(ovf.item()) == 0 and int(nu.item()) == cap and thr.cpu().numpy()[0] == np.float32(5000 + math.floor(0.3 * cap))
 
 
 @pytest.mark.parametrize("hs,ws,h,w", [(480, 640, 968, 1296), (48, 64, 97, 131), (120, 160, 120, 160), (100, 90, 37, 41)])

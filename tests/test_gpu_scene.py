@@ -570,8 +570,9 @@ def test_overlapped_ingestion_equals_prepare_scene(api):
 
 
 def test_value_set_threshold_in_the_scene_call(api, monkeypatch):
-    """BFF_FILTER_SET=1: bff_scene_project takes the point-filter threshold from the set of distinct values
-    (bff_point_threshold_pairs) instead of sorting all values -- same threshold bits, same results."""
+    """bff_scene_project takes the point-filter threshold from the set of distinct values (bff_point_threshold_pairs:
+    two launches) -- same threshold bits and results as sorting all values (BFF_FILTER_SORT=1, the 12-launch path it
+    falls back to when a scene has more distinct values than the set holds)."""
     projection, _ = api
     from beyond_fixed_forms_amd.scene import prepare_scene
     from beyond_fixed_forms_amd.synthetic import make_scene
@@ -579,13 +580,37 @@ def test_value_set_threshold_in_the_scene_call(api, monkeypatch):
         scene = make_scene("tiny", seed=71)
         cfg = cfg_for(scene, **mode_over)
         ds = prepare_scene(scene, cfg, device=DEV)
-        monkeypatch.delenv("BFF_FILTER_SET", raising=False)
+        monkeypatch.delenv("BFF_FILTER_SORT", raising=False)
         a = projection.run_projection(ds, cfg)
-        monkeypatch.setenv("BFF_FILTER_SET", "1")
+        monkeypatch.setenv("BFF_FILTER_SORT", "1")
         b = projection.run_projection(ds, cfg)
         assert a.debug["path"] == b.debug["path"] == "fast"
         assert np.float32(a.debug["thr"]).tobytes() == np.float32(b.debug["thr"]).tobytes()
         assert torch.equal(a.rows, b.rows) and torch.equal(a.conf, b.conf) and list(a.groups) == list(b.groups)
+
+
+def test_more_distinct_filter_values_than_the_set_holds(api):
+    """A scene whose filter statistic takes more distinct values than the merging set accepts (forced here by shrinking
+    the set to 3 values): the header's overflow word makes the host re-issue the scene with the sorting formulation --
+    same results as the oracle."""
+    projection, _ = api
+    from beyond_fixed_forms_amd import _lib
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    from beyond_fixed_forms_amd.synthetic import make_scene
+    scene = make_scene("tiny", seed=72)
+    cfg = cfg_for(scene)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = pref.project_scene_ref(scene, cfg)
+    ds = prepare_scene(scene, cfg, device=DEV)
+    lib = _lib.load()
+    assert lib.bff_point_threshold_capacity_set(3) == 3
+    try:
+        res = projection.run_projection(ds, cfg)
+    finally:
+        lib.bff_point_threshold_capacity_set(0)
+    assert res.debug["path"] == "fast" and ds.__dict__.get("_filter_sort") is True
+    same(res.to_dict(), exp)
 
 
 RAW_DEPTH_CASES = {
