@@ -157,12 +157,24 @@ __global__ __launch_bounds__(1024) void merge_select_kernel(const uint32_t *__re
     for (uint32_t q = tid; q < kSetSlots; q += 1024) set[q] = kHashEmpty;
     if (tid == 0) { s_count = 0; s_full = 0; }
     __syncthreads();
-    // wave w merges slices w, w + 16, ...; lanes stride over a slice's values
+    // wave w merges slices w, w + 16, ...: a slice's <= 1024 values are fetched in ONE round trip (16 per lane, all
+    // loads in flight together; the next slice's length with them) -- 16 waves walking their slices value by value
+    // would spend the kernel waiting for ~10^2 dependent global loads each -- then inserted out of registers
+    constexpr int kPerLane = 1024 / kWave;
+    uint32_t cnt = wave < n_slices ? slices[(int64_t)wave * kSliceWords] : 0;
     for (int b = wave; b < n_slices; b += 16) {
         const uint32_t *sl = slices + (int64_t)b * kSliceWords;
-        const uint32_t cnt = sl[0];
-        for (uint32_t k = lane; k < cnt; k += kWave) {
-            const uint32_t bits = sl[1 + k];
+        uint32_t v[kPerLane];
+#pragma unroll
+        for (int q = 0; q < kPerLane; ++q) {
+            const uint32_t k = lane + kWave * q;
+            v[q] = k < cnt ? sl[1 + k] : kHashEmpty;
+        }
+        const uint32_t cnt_next = b + 16 < n_slices ? slices[(int64_t)(b + 16) * kSliceWords] : 0;
+#pragma unroll
+        for (int q = 0; q < kPerLane; ++q) {
+            const uint32_t bits = v[q];
+            if (bits == kHashEmpty) continue;
             uint32_t h = (bits * 2654435761u) >> (32 - 15);
             for (uint32_t probe = 0; probe < kSetSlots; ++probe) {
                 uint32_t old = set[h];
@@ -175,6 +187,7 @@ __global__ __launch_bounds__(1024) void merge_select_kernel(const uint32_t *__re
                 h = (h + 1) & (kSetSlots - 1);
             }
         }
+        cnt = cnt_next;
     }
     __syncthreads();
     const uint32_t n = s_count;

@@ -304,8 +304,8 @@ def _fast_back(fr: _Front, stage1, want_groups) -> Stage2Result:
                            HDR_SIZES, HDR_THR)
     ds, cfg, dbg = fr.ds, fr.cfg, fr.dbg
     h = fr.fast
-    ws, both, s1_rows = h["ws"], h["both"], h["s1_rows"]
     hdr = pipeline.collect(h)                                        # the one synchronisation of the scene
+    ws, both, s1_rows = h["ws"], h["both"], h["s1_rows"]             # (after it: a re-issued scene has a new `both`)
     dev = ds.xyz.device
     n, nw = ds.n_points, ds.nw
     k_all, flags = int(hdr[HDR_K]), int(hdr[HDR_K + 1])

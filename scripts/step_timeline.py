@@ -1,5 +1,6 @@
 """From a rocprofv3 kernel trace of bench.py: timeline of the LAST n steps (kernel start offsets, durations, idle
-gaps), every kernel of the process listed (library sorts and fills included).  usage: step_timeline.py <dir> [n=1]"""
+gaps), every kernel of the process listed (library sorts and fills included).  usage: step_timeline.py <dir> [n=1] [first]
+(first: index of the first step to print instead of the last n -- bench.py runs diagnostic launches after its timed loop)"""
 import csv, glob, os, sys
 src = sys.argv[1]
 n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -8,7 +9,8 @@ rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step starts at rle_to_maskbits
 starts = [i for i, r in enumerate(rows) if "rle_to_maskbits" in r["Kernel_Name"]]
-for si in range(max(0, len(starts) - n_last), len(starts)):
+first = int(sys.argv[3]) if len(sys.argv) > 3 else max(0, len(starts) - n_last)
+for si in range(first, min(len(starts), first + n_last)):
     a = starts[si]
     b = starts[si + 1] if si + 1 < len(starts) else len(rows)
     step = rows[a:b]
