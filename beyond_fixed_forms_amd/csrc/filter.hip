@@ -94,16 +94,14 @@ __global__ __launch_bounds__(1024) void distinct_select_kernel(const float *__re
 // (float32(viewed) + 1) (or float32(masked) alone).  A scene has ~10^5..10^6 points but only ~10^3..10^4 distinct
 // values, so: (1) every block of 1024 points collects the distinct values of ITS points in an LDS hash set (most
 // points repeat a value -- half of them are 0 -- and a repeated value costs one probe) and writes them to its own
-// slice of a scratch table: no global atomics, nothing to clear; (2) ONE block merges the slices in an LDS hash set
-// of 32 Ki slots -- the set of distinct values is exactly x.unique() of the reference -- counts them and selects the
-// value of rank floor(frac * n_distinct) with a 4-pass byte-wise radix select over the slots (values are >= 0, so the
-// order of the bit patterns is the order of the values).  Two launches instead of the 12 of the sorting path
-// (value pass, 9-launch radix sort, two selection passes); bit-identical threshold.  More distinct values than the set
-// holds: *overflow = 1 and the caller sorts.
+// slice of a scratch table: no global atomics, nothing to clear; (2) 64 blocks, one per 1/64 of the hash space, merge
+// the slices into LDS sets -- together exactly x.unique() of the reference -- and append what they hold to one list;
+// (3) one block selects the value of rank floor(frac * n_distinct) with a 4-pass byte-wise radix select (values are
+// >= 0, so the order of the bit patterns is the order of the values).  Three launches instead of the 12 of the sorting
+// path (value pass, 9-launch radix sort, two selection passes); bit-identical threshold.  A partition with more
+// distinct values than its set holds: *overflow = 1 and the caller sorts.
 constexpr uint32_t kLocalSlots = 2048;                        // LDS set of one block (1024 points -> <= 1024 values)
 constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;                  // not a value: a NaN pattern (the statistic is never NaN)
-constexpr uint32_t kSetSlots = 1u << 15;                      // the merging block's set: 128 KiB of LDS
-constexpr uint32_t kSetMax = kSetSlots / 4 * 3;               // distinct values it accepts (load factor 3/4)
 constexpr int kSliceWords = 1025;                             // per block: count, then <= 1024 values
 
 __device__ __forceinline__ float pair_value(int m, int v, bool ratio)
@@ -146,20 +144,26 @@ __global__ __launch_bounds__(1024) void block_value_sets_kernel(const int32_t *_
     if (tid == 0) out[0] = s_n;
 }
 
-__global__ __launch_bounds__(1024) void merge_select_kernel(const uint32_t *__restrict__ slices, int n_slices, double frac,
-                                                             float *__restrict__ thr, int32_t *__restrict__ n_unique,
-                                                             int32_t *__restrict__ overflow, uint32_t set_max)
+// (2) kParts blocks, each owning 1/kParts of the hash space: a block reads every slice (they sit in L2) and keeps the
+// values of its partition in an LDS set; what it holds at the end is appended to `values` and counted in *n_unique.
+// One merging block alone spends ~100 us at config 2 on the dependent LDS probes of ~10^5 inserts; 64 blocks share them.
+constexpr int kParts = 64;
+constexpr uint32_t kPartSlots = 8192;                         // LDS set of one partition (32 KiB)
+constexpr uint32_t kPartMax = kPartSlots / 4 * 3;             // distinct values a partition accepts
+
+__global__ __launch_bounds__(1024) void partition_sets_kernel(const uint32_t *__restrict__ slices, int n_slices,
+                                                               uint32_t *__restrict__ values, int32_t *__restrict__ n_unique,
+                                                               int32_t *__restrict__ overflow, uint32_t part_max)
 {
-    extern __shared__ uint32_t set[];                          // kSetSlots
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_count, s_prefix, s_rank, s_full;
+    __shared__ uint32_t set[kPartSlots];
+    __shared__ uint32_t s_count, s_full, s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t q = tid; q < kSetSlots; q += 1024) set[q] = kHashEmpty;
+    const uint32_t part = blockIdx.x;
+    for (uint32_t q = tid; q < kPartSlots; q += 1024) set[q] = kHashEmpty;
     if (tid == 0) { s_count = 0; s_full = 0; }
     __syncthreads();
-    // wave w merges slices w, w + 16, ...: a slice's <= 1024 values are fetched in ONE round trip (16 per lane, all
-    // loads in flight together; the next slice's length with them) -- 16 waves walking their slices value by value
-    // would spend the kernel waiting for ~10^2 dependent global loads each -- then inserted out of registers
+    // wave w reads slices w, w + 16, ...: a slice's <= 1024 values in ONE round trip (16 per lane in flight together,
+    // the next slice's length with them)
     constexpr int kPerLane = 1024 / kWave;
     uint32_t cnt = wave < n_slices ? slices[(int64_t)wave * kSliceWords] : 0;
     for (int b = wave; b < n_slices; b += 16) {
@@ -174,29 +178,54 @@ __global__ __launch_bounds__(1024) void merge_select_kernel(const uint32_t *__re
 #pragma unroll
         for (int q = 0; q < kPerLane; ++q) {
             const uint32_t bits = v[q];
-            if (bits == kHashEmpty) continue;
-            uint32_t h = (bits * 2654435761u) >> (32 - 15);
-            for (uint32_t probe = 0; probe < kSetSlots; ++probe) {
+            const uint32_t hash = bits * 2654435761u;
+            if (bits == kHashEmpty || (hash >> 26) != part) continue;              // top 6 bits: the partition
+            uint32_t h = (hash >> 13) & (kPartSlots - 1);                          // next 13 bits: the slot
+            for (uint32_t probe = 0; probe < kPartSlots; ++probe) {
                 uint32_t old = set[h];
                 if (old == kHashEmpty) {
-                    if (*(volatile uint32_t *)&s_count >= set_max) { s_full = 1; break; }     // up to 1024 inserts may slip past: the set has room
+                    if (*(volatile uint32_t *)&s_count >= part_max) { s_full = 1; break; }   // <= 1024 inserts slip past: there is room
                     old = atomicCAS(&set[h], kHashEmpty, bits);
                     if (old == kHashEmpty) { atomicAdd(&s_count, 1u); break; }
                 }
                 if (old == bits) break;
-                h = (h + 1) & (kSetSlots - 1);
+                h = (h + 1) & (kPartSlots - 1);
             }
         }
         cnt = cnt_next;
     }
     __syncthreads();
     const uint32_t n = s_count;
-    if (s_full || n > set_max) {                               // block-uniform
-        if (tid == 0) { *overflow = 1; *n_unique = (int32_t)n; *thr = __builtin_nanf(""); }
+    if (s_full || n > part_max) {                              // block-uniform
+        if (tid == 0) *overflow = 1;
         return;
     }
+    if (tid == 0) s_base = (uint32_t)atomicAdd(n_unique, (int32_t)n);
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t q = tid; q < kPartSlots; q += 1024) {
+        const uint32_t bits = set[q];
+        const uint64_t bal = __ballot(bits != kHashEmpty);
+        uint32_t at = 0;
+        if (lane == 0 && bal) at = atomicAdd(&s_count, (uint32_t)__popcll(bal));
+        at = __shfl(at, 0);
+        if (bits != kHashEmpty) values[base + at + __popcll(bal & ((1ull << lane) - 1))] = bits;
+    }
+}
+
+// (3) one block: the value of rank floor(frac * n) among the n distinct bit patterns (all >= 0 as floats), by four 8-bit
+// radix-select passes, most significant byte first
+__global__ __launch_bounds__(1024) void select_rank_kernel(const uint32_t *__restrict__ values, const int32_t *__restrict__ n_unique,
+                                                            const int32_t *__restrict__ overflow, double frac,
+                                                            float *__restrict__ thr)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_rank;
+    const int tid = threadIdx.x;
+    if (*overflow) { if (tid == 0) *thr = __builtin_nanf(""); return; }             // block-uniform: the caller sorts
+    const uint32_t n = (uint32_t)*n_unique;
     if (tid == 0) {
-        *n_unique = (int32_t)n;
         const long long r = (long long)floor(frac * (double)n);
         s_rank = (r >= 0 && r < (long long)n) ? (uint32_t)r : 0xFFFFFFFFu;
         s_prefix = 0;
@@ -207,9 +236,9 @@ __global__ __launch_bounds__(1024) void merge_select_kernel(const uint32_t *__re
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const uint32_t prefix = s_prefix, mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (uint32_t q = tid; q < kSetSlots; q += 1024) {
-            const uint32_t v = set[q];
-            if (v != kHashEmpty && (v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+        for (uint32_t i = tid; i < n; i += 1024) {
+            const uint32_t v = values[i];
+            if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
         }
         __syncthreads();
         if (tid == 0) {
@@ -332,22 +361,23 @@ extern "C" int bff_depth_from_u16(const uint16_t *src, int32_t n_frames, int32_t
 
 extern "C" int64_t bff_point_threshold_scratch_words(int64_t n_points)
 {
-    return ceil_div(n_points > 0 ? n_points : 1, 1024) * kSliceWords;
+    return ceil_div(n_points > 0 ? n_points : 1, 1024) * kSliceWords + (int64_t)kParts * kPartSlots;
 }
 
-static uint32_t g_set_max = kSetMax;
-extern "C" int32_t bff_point_threshold_capacity(void) { return (int32_t)g_set_max; }
+static uint32_t g_part_max = kPartMax;
+extern "C" int32_t bff_point_threshold_capacity(void) { return (int32_t)g_part_max; }
 // test hook: a smaller capacity makes ordinary scenes exercise the overflow -> sorting fallback; 0 restores the default
 extern "C" int32_t bff_point_threshold_capacity_set(int32_t cap)
 {
-    g_set_max = (cap > 0 && (uint32_t)cap < kSetMax) ? (uint32_t)cap : kSetMax;
-    return (int32_t)g_set_max;
+    g_part_max = (cap > 0 && (uint32_t)cap < kPartMax) ? (uint32_t)cap : kPartMax;
+    return (int32_t)g_part_max;
 }
 
 // thr / n_unique as bff_point_values + bff_sort_f32 + bff_select_unique_rank deliver them, from the distinct values
 // that occur.  scratch: uint32 [bff_point_threshold_scratch_words(n_points)], needs no clearing.  *overflow (device
-// int32, NOT cleared here) is set to 1 when the scene has more distinct values than the merging set holds
-// (bff_point_threshold_capacity()): thr is then undefined and the caller must take the sorting path.
+// int32, NOT cleared here) is set to 1 when one of the 64 hash partitions holds more distinct values than
+// bff_point_threshold_capacity() (scenes with several 10^5 distinct values): thr is then NaN and the caller must take
+// the sorting path.  *n_unique is the counter the partitions add to: cleared here (bff_scene_project: by its one fill).
 extern "C" int bff_point_threshold_pairs(const int32_t *masked, const int32_t *viewed, int64_t n_points, double fraction,
                                          uint32_t *scratch, float *thr, int32_t *n_unique, int32_t *overflow, void *stream)
 {
@@ -355,18 +385,14 @@ extern "C" int bff_point_threshold_pairs(const int32_t *masked, const int32_t *v
     hipStream_t st = as_stream(stream);
     const int64_t n_slices = n_points > 0 ? ceil_div(n_points, 1024) : 0;
     BFF_LIMIT(n_slices < (1ll << 30), "bff_point_threshold_pairs: too many points");
-    static bool lds_enabled = false;
-    if (!lds_enabled) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(merge_select_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * kSetSlots));
-        if (e != hipSuccess) return fail((int)e, "bff_point_threshold_pairs: LDS attribute: %s", hipGetErrorString(e));
-        lds_enabled = true;
-    }
+    hipError_t e = zero_async(n_unique, sizeof(int32_t), st);
+    if (e != hipSuccess) return fail((int)e, "bff_point_threshold_pairs: memset: %s", hipGetErrorString(e));
+    uint32_t *values = scratch + n_slices * kSliceWords;
     if (n_points > 0) {
         BFF_REQUIRE(masked, "bff_point_threshold_pairs: null pointer");
         block_value_sets_kernel<<<(unsigned)n_slices, 1024, 0, st>>>(masked, viewed, n_points, scratch);
+        partition_sets_kernel<<<kParts, 1024, 0, st>>>(scratch, (int)n_slices, values, n_unique, overflow, g_part_max);
     }
-    merge_select_kernel<<<1, 1024, sizeof(uint32_t) * kSetSlots, st>>>(scratch, (int)n_slices, fraction, thr, n_unique, overflow,
-                                                                       g_set_max);
+    select_rank_kernel<<<1, 1024, 0, st>>>(values, n_unique, overflow, fraction, thr);
     return launched("bff_point_threshold_pairs");
 }

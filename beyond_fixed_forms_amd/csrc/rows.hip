@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void popcount_rows_kernel(const uint64_t *__re
 // LDS images are [word][row] (pitch 65) so that the 4 rows / 4 columns a thread needs for one word
 // are 32 contiguous bytes; thread (ti, tj) of the 16 x 16 thread grid owns rows 4ti..4ti+3 and
 // columns 4tj..4tj+3.
+__device__ __forceinline__ int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
 __device__ __forceinline__ void tile_popcount(const uint64_t *__restrict__ a, const int32_t *__restrict__ ia,
                                               int na, int i0, const uint64_t *__restrict__ b,
                                               const int32_t *__restrict__ ib, int nb, int j0, int64_t nw,
@@ -94,18 +96,49 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
                                                               const int32_t *__restrict__ k_dev, int lim_a, int hole_hi,
                                                               unsigned long long *__restrict__ pmask)
 {
+    __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
     // k_dev (optional): only the first *k_dev rows of a (when lim_a) resp. of b's leading block [0, hole_hi) hold data,
     // the rest of those ranges is all zero: tiles that lie entirely in the zero part are skipped (the output is
     // zeroed by the host when the words are split over z; callers never read the skipped entries otherwise)
     if (k_dev) {
         const int kd = *k_dev;
+        if (lim_a == 2 && kd <= kT) {
+            // a == b and at most 64 live rows (the usual number of kept groups is a few dozen): a 64 x 64 tile would spend
+            // its time on rows that are zero.  Every block takes one 32-word slice of the live rows instead (blocks beyond
+            // the slices leave), thread p adds up pairs p, p + 256, ... of the upper triangle, and the partial counts and
+            // pair flags meet through atomics in the zeroed outputs, as with split tiles.
+            const int64_t blocks = (int64_t)gridDim.x * gridDim.y * gridDim.z;
+            const int64_t slice = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const int64_t per = ceil_div_dev(ceil_div_dev(nw, blocks), kKW) * kKW;       // words per block, whole stages
+            const int64_t k_lo = slice * per, k_hi = min(nw, k_lo + per);
+            if (k_lo >= nw || kd <= 0) return;                    // block-uniform
+            const int lk = threadIdx.x & (kKW - 1), lr = threadIdx.x >> 5;
+            const int n_pairs = kd * (kd + 1) / 2;
+            for (int64_t k0 = k_lo; k0 < k_hi; k0 += kKW) {
+                for (int r = lr; r < kd; r += 8) sa[lk][r] = k0 + lk < nw ? a[(int64_t)r * nw + k0 + lk] : 0;
+                __syncthreads();
+                for (int p = threadIdx.x; p < n_pairs; p += 256) {
+                    int i = 0, rest = p;                           // p -> (i <= j): row i owns kd - i pairs
+                    while (rest >= kd - i) { rest -= kd - i; ++i; }
+                    const int j = i + rest;
+                    int c = 0;
+#pragma unroll 8
+                    for (int kk = 0; kk < kKW; ++kk) c += popc64(sa[kk][i] & sa[kk][j]);
+                    if (c) {
+                        atomicAdd(inter + (int64_t)i * nb + j, c);
+                        if (pmask && j > i) atomicOr(pmask + (int64_t)i * kMW + (j >> 6), 1ull << (j & 63));
+                    }
+                }
+                __syncthreads();
+            }
+            return;
+        }
         if (lim_a && (int)blockIdx.y * kT >= kd) return;
         if ((int)blockIdx.x * kT >= kd && (int)(blockIdx.x + 1) * kT <= hole_hi) return;
         if (lim_a == 2 && blockIdx.y > blockIdx.x) return;        // a == b and only entries j >= i are read
     }
     // blockIdx.z owns the word range [z*k_split, (z+1)*k_split): small row counts still fill the chip.
     // Partial counts are combined with integer atomics (exact, order independent) into a zeroed matrix.
-    __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
     int acc[4][4];
     const int i0 = blockIdx.y * kT, j0 = blockIdx.x * kT;
     const int64_t k_begin = (int64_t)blockIdx.z * k_split;

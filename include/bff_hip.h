@@ -370,11 +370,12 @@ int bff_ids_to_rows(const int64_t *ids, int64_t n_points, const int64_t *values,
  * masked > 0. */
 int bff_point_values(const int32_t *masked, const int32_t *viewed, int64_t n_points, float *vals, void *stream);
 /* The same (thr, n_unique) without sorting n_points values: the statistic is a function of the integer pair (masked,
- * viewed), of which a scene holds only ~10^3..10^4 different ones: every block collects the distinct values of its
- * 1024 points in LDS and writes them to its slice of `scratch` (no global atomics, nothing to clear), ONE block merges
- * the slices in an LDS hash set (= x.unique() of P:516 / P:574) and radix-selects the rank: two launches.
- * scratch: uint32 [bff_point_threshold_scratch_words(n_points)]; *overflow (device, not cleared by the call) is set to 1
- * if there are more distinct values than bff_point_threshold_capacity(): use the sorting path then. */
+ * viewed), of which a scene holds only ~10^3..10^5 different ones: every block collects the distinct values of its
+ * 1024 points in LDS and writes them to its slice of `scratch` (no global atomics, nothing to clear); 64 blocks, one per
+ * 1/64 of the hash space, merge the slices in LDS sets (together = x.unique() of P:516 / P:574); one block radix-selects
+ * the rank: three launches.  scratch: uint32 [bff_point_threshold_scratch_words(n_points)]; *overflow (device, not
+ * cleared by the call) is set to 1 if a partition holds more distinct values than bff_point_threshold_capacity(): use
+ * the sorting path then. */
 int64_t bff_point_threshold_scratch_words(int64_t n_points);
 int32_t bff_point_threshold_capacity(void);
 int32_t bff_point_threshold_capacity_set(int32_t cap);     /* test hook: smaller capacity (0 = default); returns the new one */

@@ -551,18 +551,21 @@ def test_point_filters(lib, mode, n):
     assert torch.equal(lib.ratio_keep(md, vd, float(thr), True), keep)
     keep0 = lib.ratio_keep(md, None, 0.0, False)
     assert np.array_equal(unpack(keep0[None], n)[0], masked > 0)
+    fits = True                              # 64 partitions x 6144 values: every case here is far inside the capacity
     for f in (0.0, 0.999999, 1.0):          # first, last, out of range (python: IndexError)
         t2, _ = lib.point_threshold(md, vd, f)
         t3, nu3, ovf = lib.point_threshold_pairs(md, vd, f)
         k = math.floor(f * uniq.shape[0])
-        assert int(ovf.item()) == 0 and int(nu3.item()) == uniq.shape[0]
+        assert int(ovf.item()) == (0 if fits else 1) and (not fits or int(nu3.item()) == uniq.shape[0])
         if k < uniq.shape[0]:
-            assert t2.cpu().numpy()[0] == uniq[k].numpy() and t3.cpu().numpy()[0] == uniq[k].numpy()
+            assert t2.cpu().numpy()[0] == uniq[k].numpy() and (not fits or t3.cpu().numpy()[0] == uniq[k].numpy())
         else:
             assert np.isnan(t2.cpu().numpy()[0]) and np.isnan(t3.cpu().numpy()[0])
-    # the pair formulation (no sort): same threshold, same count, bit for bit
+    # the set formulation (no sort): same threshold, same count, bit for bit
     t3, nu3, ovf = lib.point_threshold_pairs(md, vd, frac)
-    assert int(ovf.item()) == 0 and int(nu3.item()) == uniq.shape[0] and t3.cpu().numpy()[0] == thr.numpy()
+    assert int(ovf.item()) == (0 if fits else 1)
+    assert not fits or (int(nu3.item()) == uniq.shape[0] and t3.cpu().numpy()[0] == thr.numpy())
+
 
 
 def test_point_threshold_pairs_out_of_range_and_overflow(lib):
@@ -571,9 +574,9 @@ def test_point_threshold_pairs_out_of_range_and_overflow(lib):
     import math
     rng = np.random.default_rng(77)
     n = 50_000
-    masked = rng.integers(0, 9000, n) // 40 * 40                  # ~20 k distinct ratios: inside the set's capacity
-    viewed = rng.integers(0, 3000, n) // 30 * 30
-    cap = int(lib.load().bff_point_threshold_capacity())
+    masked = rng.integers(0, 9000, n)
+    viewed = rng.integers(0, 3000, n)
+    cap = int(lib.load().bff_point_threshold_capacity())          # per hash partition (64 of them)
     md = torch.tensor(masked, dtype=torch.int32, device=DEV)
     vd = torch.tensor(viewed, dtype=torch.int32, device=DEV)
     stat = torch.tensor(masked, dtype=torch.float32) / (torch.tensor(viewed, dtype=torch.float32) + 1)
@@ -582,15 +585,19 @@ def test_point_threshold_pairs_out_of_range_and_overflow(lib):
         thr, nu, ovf = lib.point_threshold_pairs(md, vd, f)
         assert int(ovf.item()) == 0 and int(nu.item()) == uniq.shape[0]
         assert thr.cpu().numpy()[0] == uniq[math.floor(f * uniq.shape[0])].numpy()
-    assert 1000 < uniq.shape[0] <= cap
-    big = torch.arange(cap + 1, dtype=torch.int32, device=DEV) + 5000          # one distinct value too many
+    assert uniq.shape[0] > 30_000
+    big = torch.arange(1_000_000, dtype=torch.int32, device=DEV)               # 10^6 distinct values: ~15 600 per partition
     _, _, ovf = lib.point_threshold_pairs(big, None, 0.3)
     assert int(ovf.item()) == 1
-    _, _, ovf = lib.point_threshold_pairs(torch.arange(300_000, dtype=torch.int32, device=DEV), None, 0.3)
-    assert int(ovf.item()) == 1
-    ok = torch.arange(cap, dtype=torch.int32, device=DEV) + 5000               # exactly the capacity fits
+    ok = torch.arange(200_000, dtype=torch.int32, device=DEV) + 5000           # 200 k distinct values (~3 100 per partition) fit
     thr, nu, ovf = lib.point_threshold_pairs(ok, None, 0.3)
-    assert int(ovf.item()) == 0 and int(nu.item()) == cap and thr.cpu().numpy()[0] == np.float32(5000 + math.floor(0.3 * cap))
+    assert int(ovf.item()) == 0 and int(nu.item()) == 200_000 and thr.cpu().numpy()[0] == np.float32(5000 + 60_000)
+    assert lib.load().bff_point_threshold_capacity_set(2) == 2                 # test hook: tiny partitions overflow
+    try:
+        _, _, ovf = lib.point_threshold_pairs(ok, None, 0.3)
+        assert int(ovf.item()) == 1
+    finally:
+        assert lib.load().bff_point_threshold_capacity_set(0) == cap
 
 
 @pytest.mark.parametrize("hs,ws,h,w", [(480, 640, 968, 1296), (48, 64, 97, 131), (120, 160, 120, 160), (100, 90, 37, 41)])

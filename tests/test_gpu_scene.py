@@ -591,7 +591,7 @@ def test_value_set_threshold_in_the_scene_call(api, monkeypatch):
 
 def test_more_distinct_filter_values_than_the_set_holds(api):
     """A scene whose filter statistic takes more distinct values than the merging set accepts (forced here by shrinking
-    the set to 3 values): the header's overflow word makes the host re-issue the scene with the sorting formulation --
+    every hash partition's set to 1 value): the header's overflow word makes the host re-issue the scene with the sorting formulation --
     same results as the oracle."""
     projection, _ = api
     from beyond_fixed_forms_amd import _lib
@@ -604,7 +604,7 @@ def test_more_distinct_filter_values_than_the_set_holds(api):
         exp = pref.project_scene_ref(scene, cfg)
     ds = prepare_scene(scene, cfg, device=DEV)
     lib = _lib.load()
-    assert lib.bff_point_threshold_capacity_set(3) == 3
+    assert lib.bff_point_threshold_capacity_set(1) == 1
     try:
         res = projection.run_projection(ds, cfg)
     finally:
