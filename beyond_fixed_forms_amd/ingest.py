@@ -42,8 +42,12 @@ def host_lib():
         lib.bff_host_pack_rles.restype = c_longlong
         lib.bff_host_pack_frames.argtypes = [py_object, c_void_p, c_longlong, c_int]
         lib.bff_host_pack_frames.restype = c_longlong
+        lib.bff_host_png_size.argtypes = [ctypes.c_char_p, c_void_p]
+        lib.bff_host_png_size.restype = c_int
+        lib.bff_host_decode_depth_pngs.argtypes = [py_object, c_void_p, c_int, c_int, c_void_p, c_int]
+        lib.bff_host_decode_depth_pngs.restype = c_longlong
         lib.bff_host_abi.restype = c_int
-        if lib.bff_host_abi() != 1:
+        if lib.bff_host_abi() != 2:
             raise _lib.BffLibraryError(f"{HOST_LIB_PATH}: unexpected ABI; rebuild")
         _host = lib
     return _host
@@ -310,13 +314,16 @@ class Ingestor:
         _lib.load()
 
     def _work(self, scene):
-        if callable(scene):                           # a loader (e.g. io.load_scene of one scene): file reads run here too
-            scene = scene()
         tl = self.local
         if not hasattr(tl, "stream"):
             torch.cuda.set_device(self.device)
             tl.stream = torch.cuda.Stream(device=self.device)
             tl.staging = Staging()
+        if callable(scene):                           # a loader (e.g. io.load_scene of one scene): file reads run here too
+            try:                                      # loaders that take `staging` decode depth straight into pinned memory
+                scene = scene(staging=tl.staging)
+            except TypeError:
+                scene = scene()
         with torch.cuda.stream(tl.stream):
             ds = prepare_scene_fast(scene, self.cfg, self.device, self.with_viewed, tl.staging, self.native_threads)
             st1 = None

@@ -90,10 +90,43 @@ def load_depth_raw(path: str) -> np.ndarray:
     return d
 
 
-def load_scene(cfg, cls: str, scene_id: str, depth_on_device: bool = False) -> SceneInputs:
+def decode_depth_pngs(paths, out: np.ndarray = None, n_threads: int = 4) -> np.ndarray:
+    """16-bit depth PNGs (P:431-433) -> uint16 [F][h][w]: the whole batch through the native decoder of libbff_host.so
+    (inflate + the five PNG row filters on native threads, GIL released, written straight into `out` -- e.g. pinned
+    staging -- when given); files it declines (another bit depth or colour type, interlaced, damaged, a different size)
+    are decoded by PIL, which also decides whether such a file is an error."""
+    import ctypes
+    from .ingest import host_lib
+    lib = host_lib()
+    paths = [os.fspath(p) for p in paths]
+    if not paths:
+        return np.zeros((0, 0, 0), np.uint16) if out is None else out[:0]
+    hw = (ctypes.c_int32 * 2)()
+    if lib.bff_host_png_size(paths[0].encode(), ctypes.cast(hw, ctypes.c_void_p)) != 0:
+        first = load_depth_raw(paths[0])                                   # PIL decides what the first file is
+        hw[0], hw[1] = first.shape
+    h, w = int(hw[0]), int(hw[1])
+    if out is None:
+        out = np.empty((len(paths), h, w), dtype=np.uint16)
+    frames = out.reshape(-1)[:len(paths) * h * w].reshape(len(paths), h, w)
+    status = np.zeros(len(paths), dtype=np.int32)
+    got = lib.bff_host_decode_depth_pngs(paths, frames.ctypes.data, h, w, status.ctypes.data, int(n_threads))
+    if got < 0:
+        raise ValueError("bff_host_decode_depth_pngs: bad arguments")
+    for i in np.flatnonzero(status):                                       # declined: the general decoder
+        d = load_depth_raw(paths[i])
+        if d.shape != (h, w):
+            raise ValueError(f"{paths[i]}: depth frame of size {d.shape}, the scene's frames are {(h, w)}")
+        frames[i] = d
+    return frames
+
+
+def load_scene(cfg, cls: str, scene_id: str, depth_on_device: bool = False, staging=None) -> SceneInputs:
     """Everything P:370-400 + the per-frame files of P:422-436 and P:526-563 for one scene.
-    depth_on_device: keep the depth frames as raw uint16 (`SceneInputs.depths_raw`); prepare_scene uploads them
-    as they are and does /1000 + resize with bff_depth_from_u16."""
+    depth_on_device: keep the depth frames as raw uint16 (`SceneInputs.depths_raw`), decoded as one batch by the native
+    PNG decoder; prepare_scene uploads them as they are and the sweep does /1000 + resize per point.  staging (an
+    ingest.Staging, given by the loader thread that will upload the scene): the frames are decoded straight into its
+    pinned "depth" buffer in upload order, so the upload needs no further copy."""
     scene_dir = os.path.join(cfg.scene_2d_dir, scene_id)
     cam_intr = read_matrix_txt(os.path.join(scene_dir, "intrinsic", "intrinsic_color.txt"))     # P:376
     points = np.load(os.path.join(cfg.scene_npy_dir, f"{scene_id}.npy"))                         # P:387
@@ -103,15 +136,30 @@ def load_scene(cfg, cls: str, scene_id: str, depth_on_device: bool = False) -> S
     color_dir = os.path.join(scene_dir, "color")
     color_files = [f for f in os.listdir(color_dir) if f.endswith(".jpg")] if os.path.isdir(color_dir) else []
     from .scene import viewed_frame_ids
-    need = {fr["frame_id"][:-4] for fr in mask_2d}
+    # frames in upload order: mask frames in list order, then the frames only the detection-ratio sweep looks at
+    need = list(dict.fromkeys(fr["frame_id"][:-4] for fr in mask_2d))
     if (not cfg.if_occurance_threshold) and cfg.if_detected_ratio_threshold:
-        need |= set(viewed_frame_ids(color_files, cfg.downsample_ratio))
+        need = list(dict.fromkeys(need + viewed_frame_ids(color_files, cfg.downsample_ratio)))
     w, h = int(cfg.width_2d), int(cfg.height_2d)
     poses = {f: read_matrix_txt(os.path.join(scene_dir, "pose", f"{f}.txt")) for f in need}      # P:422
     if depth_on_device:
-        raw = {f: load_depth_raw(os.path.join(scene_dir, "depth", f"{f}.png")) for f in need}
-        return SceneInputs(scene_id=scene_id, points=points, cam_intr=cam_intr, poses=poses, depths={}, depths_raw=raw,
-                           mask_2d=mask_2d, color_files=color_files, height=h, width=w)
+        paths = [os.path.join(scene_dir, "depth", f"{f}.png") for f in need]
+        out = None
+        if staging is not None and need:
+            import ctypes
+            from .ingest import host_lib
+            hw = (ctypes.c_int32 * 2)()
+            if host_lib().bff_host_png_size(paths[0].encode(), ctypes.cast(hw, ctypes.c_void_p)) == 0:
+                staging.wait()                       # the previous scene's copy out of the pinned buffer is done
+                nbytes = 2 * len(need) * int(hw[0]) * int(hw[1])
+                out = staging.get("depth", nbytes).numpy()[:nbytes].view(np.uint16)
+        frames = decode_depth_pngs(paths, out=out)
+        scene = SceneInputs(scene_id=scene_id, points=points, cam_intr=cam_intr, poses=poses, depths={},
+                            depths_raw={f: frames[i] for i, f in enumerate(need)},
+                            mask_2d=mask_2d, color_files=color_files, height=h, width=w)
+        if out is not None:
+            scene.depth_staged = (staging, list(need))
+        return scene
     depths = {f: load_depth(os.path.join(scene_dir, "depth", f"{f}.png"), w, h) for f in need}   # P:431-436
     return SceneInputs(scene_id=scene_id, points=points, cam_intr=cam_intr, poses=poses, depths=depths,
                        mask_2d=mask_2d, color_files=color_files, height=h, width=w)

@@ -47,6 +47,8 @@ class SceneInputs:
     point_object: Optional[np.ndarray] = None   # generator ground truth (not an input)
     depths_raw: Optional[Dict[str, np.ndarray]] = None   # frame id -> uint16 (h,w) millimetres as stored in the PNG;
                                                           # when given, /1000 + resize run on the device
+    depth_staged: Optional[tuple] = None                 # (ingest.Staging, frame ids): depths_raw already lies in that
+                                                          # staging's pinned "depth" buffer in this order (io.load_scene)
 
 
 def _hash32(x: torch.Tensor) -> torch.Tensor:

@@ -22,27 +22,27 @@ def timeit(name, fn, reps=10):
 o_sig = torch.argsort(sig, stable=True).to(torch.int32)
 o_mean = torch.argsort(mean_word.long()).to(torch.int32)
 o_id = torch.arange(rows.shape[0], dtype=torch.int32, device=dev)
-for name, o in (("signature", o_sig), ("mean_word", o_mean), ("identity", o_id)):
+for name, o in (("signature", o_sig),):
     for thr in (0.2, 0.9, 2.0):
         timeit(f"merge_components order={name} thr={thr}", lambda: _lib.merge_components(rows, area, ds.label_id, thr, o, cmask, hist))
 timeit("row_stats", lambda: _lib.row_stats(rows))
 timeit("argsort(sig)", lambda: torch.argsort(sig, stable=True))
 
-for cs in (0, 4, 8, 16):
+for cs in (0,):
     timeit(f"merge_components signature thr=0.2 coarse_stride={cs}", lambda: _lib.merge_components(rows, area, ds.label_id, 0.2, o_sig, cmask, hist, coarse_stride=cs))
-    d = torch.zeros(4, dtype=torch.int32, device=dev)
+    d = torch.zeros(16, dtype=torch.int32, device=dev)      # counters + phase clocks; d[15] = 0: no block timeline
     _lib.merge_components(rows, area, ds.label_id, 0.2, o_sig, cmask, hist, diag=d, coarse_stride=cs)
-    print("   coarse", cs, "tiles evaluated, chunk visits, candidate pairs, unions:", d.tolist())
-for name, o in (("signature", o_sig), ("mean_word", o_mean)):
+    print("   coarse", cs, "tiles evaluated, chunk visits, candidate pairs, unions:", d.tolist()[:4])
+for name, o in (("signature", o_sig),):
     for thr in (0.2, 0.9):
-        d = torch.zeros(4, dtype=torch.int32, device=dev)
+        d = torch.zeros(16, dtype=torch.int32, device=dev)      # counters + phase clocks; d[15] = 0: no block timeline
         _lib.merge_components(rows, area, ds.label_id, thr, o, cmask, hist, diag=d)
-        print(name, thr, "tiles evaluated, chunk visits, candidate pairs, unions:", d.tolist())
+        print(name, thr, "tiles evaluated, chunk visits, candidate pairs, unions:", d.tolist()[:4])
 
 # floor: start from the converged forest
 comp = _lib.merge_components(rows, area, ds.label_id, 0.2, o_sig, cmask, hist)
-d = torch.zeros(4, dtype=torch.int32, device=dev)
+d = torch.zeros(16, dtype=torch.int32, device=dev)      # counters + phase clocks; d[15] = 0: no block timeline
 _lib.merge_components(rows, area, ds.label_id, 0.2, o_sig, cmask, hist, diag=d, parent=comp.clone())
-print("converged start:", d.tolist())
+print("converged start: tiles evaluated, chunk visits, candidate pairs, unions:", d.tolist()[:4])
 pc = comp.clone()
 timeit("merge_components from converged forest", lambda: _lib.merge_components(rows, area, ds.label_id, 0.2, o_sig, cmask, hist, parent=pc))

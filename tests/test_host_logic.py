@@ -278,3 +278,107 @@ def test_native_run_tables_match_the_numpy_builder():
     assert ingest.host_lib().bff_host_pack_frames(frames, dst.data_ptr(), 70, 3) == 9
     assert np.array_equal(dst.numpy().view(np.uint16).reshape(9, 5, 7), np.stack(frames))
     assert ingest.host_lib().bff_host_pack_frames(frames + [np.zeros((5, 8), np.uint16)], dst.data_ptr(), 70, 2) == -1
+
+
+def _write_png16(path, img, filters, interlace=0, bitdepth=16, n_idat=2, truncate=0):
+    """A 16-bit grayscale PNG written by hand: the row filter of every row is chosen by the caller."""
+    import struct
+    import zlib
+    h, w = img.shape
+    bpp = 2 if bitdepth == 16 else 1
+    be = img.astype(">u2").tobytes() if bitdepth == 16 else img.astype(np.uint8).tobytes()
+    stride = w * bpp
+    raw, prev = bytearray(), bytes(stride)
+    for y in range(h):
+        cur = be[y * stride:(y + 1) * stride]
+        ft = filters[y]
+        out = bytearray(stride)
+        for i in range(stride):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0:
+                p = 0
+            elif ft == 1:
+                p = a
+            elif ft == 2:
+                p = b
+            elif ft == 3:
+                p = (a + b) >> 1
+            else:
+                pp = a + b - c
+                pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[i] = (cur[i] - p) & 255
+        raw.append(ft)
+        raw += out
+        prev = cur
+    chunk = lambda t, d: struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    comp = zlib.compress(bytes(raw), 6)
+    cuts = [len(comp) * k // n_idat for k in range(n_idat + 1)]
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bitdepth, 0, 0, 0, interlace)) + \
+        chunk(b"tEXt", b"k\0v") + b"".join(chunk(b"IDAT", comp[a:b]) for a, b in zip(cuts[:-1], cuts[1:])) + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(data[:len(data) - truncate] if truncate else data)
+
+
+def test_native_png_decoder_equals_pil_on_all_filter_types(tmp_path):
+    """io.decode_depth_pngs (libbff_host.so: chunk walk, inflate, the five PNG row filters at 2 bytes per pixel,
+    byte swap; native threads) against PIL and against the source arrays: every filter type alone, mixed per row,
+    several IDAT chunks, an ancillary chunk, a PIL-written file; into a caller-provided buffer (pinned staging)."""
+    from PIL import Image
+    from beyond_fixed_forms_amd import io as bio
+    rng = np.random.default_rng(3)
+    h, w = 37, 53
+    paths, imgs = [], []
+    for i in range(8):
+        img = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+        if i == 5:
+            img[:] = (np.arange(w)[None, :] * 1000 + np.arange(h)[:, None]) & 0xFFFF        # gradients: filters matter
+        filters = [i % 5] * h if i < 5 else [int(v) for v in rng.integers(0, 5, h)]
+        p = tmp_path / f"{i}.png"
+        _write_png16(p, img, filters, n_idat=1 + i % 3)
+        paths.append(str(p)); imgs.append(img)
+    Image.fromarray(imgs[0]).save(tmp_path / "pil.png")
+    paths.append(str(tmp_path / "pil.png")); imgs.append(imgs[0])
+    got = bio.decode_depth_pngs(paths, n_threads=3)
+    assert got.dtype == np.uint16 and got.shape == (len(paths), h, w)
+    for g, e, p in zip(got, imgs, paths):
+        assert np.array_equal(g, e) and np.array_equal(np.asarray(Image.open(p)), e), p
+    buf = np.zeros(len(paths) * h * w + 7, dtype=np.uint16)
+    again = bio.decode_depth_pngs(paths, out=buf, n_threads=1)
+    assert np.shares_memory(again, buf) and np.array_equal(again, got)
+    assert bio.decode_depth_pngs([]).shape[0] == 0
+
+
+def test_native_png_decoder_declines_what_it_does_not_cover(tmp_path):
+    """Files outside the decoder's scope fall to PIL, which then decides: an 8-bit image is an error for a depth
+    frame, an interlaced 16-bit image is decoded by PIL (same values), a truncated file raises; a file of another size
+    than the batch's is an error."""
+    from PIL import Image
+    from beyond_fixed_forms_amd import io as bio
+    from beyond_fixed_forms_amd.ingest import host_lib
+    import ctypes
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 65536, (20, 31)).astype(np.uint16)
+    ok = tmp_path / "ok.png"
+    _write_png16(ok, img, [4] * 20)
+    g8 = tmp_path / "g8.png"
+    Image.fromarray((img >> 8).astype(np.uint8)).save(g8)
+    hw = (ctypes.c_int32 * 2)()
+    assert host_lib().bff_host_png_size(str(g8).encode(), ctypes.cast(hw, ctypes.c_void_p)) == 3
+    assert host_lib().bff_host_png_size(str(ok).encode(), ctypes.cast(hw, ctypes.c_void_p)) == 0 and (hw[0], hw[1]) == (20, 31)
+    with pytest.raises(ValueError):
+        bio.decode_depth_pngs([str(ok), str(g8)])
+    other = tmp_path / "other.png"
+    _write_png16(other, img[:10], [0] * 10)
+    with pytest.raises(ValueError):
+        bio.decode_depth_pngs([str(ok), str(other)])
+    cut = tmp_path / "cut.png"
+    _write_png16(cut, img, [1] * 20, truncate=40)
+    with pytest.raises(Exception):
+        bio.decode_depth_pngs([str(ok), str(cut)])
+    status = np.zeros(2, np.int32)
+    out = np.zeros((2, 20, 31), np.uint16)
+    n = host_lib().bff_host_decode_depth_pngs([str(ok), str(cut)], out.ctypes.data, 20, 31, status.ctypes.data, 2)
+    assert n == 1 and status[0] == 0 and status[1] != 0 and np.array_equal(out[0], img) and not out[1].any()
