@@ -121,7 +121,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
     mask_2d = scene.mask_2d
     max_m = max((len(fr["segmented_frame_masks"]) for fr in mask_2d), default=0)
     word_bits = 32 if max_m <= 32 else 64
-    viewed = viewed_frame_ids(scene.color_files, cfg.downsample_ratio) if with_viewed else []
+    viewed = _viewed_ids_cached(scene, cfg.downsample_ratio) if with_viewed else []
     viewed_left = dict.fromkeys(viewed)
     depth_slot, depth_ids = {}, []
 
@@ -244,8 +244,11 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
         conf = torch.cat([c.reshape(-1) for c in conf_list]).cpu()
     else:
         conf = torch.zeros(0, dtype=torch.float16)
-    ids = {}
-    label_id = np.fromiter((ids.setdefault(s, len(ids)) for s in labels), dtype=np.int32, count=len(labels))
+    ids = {s: k for k, s in enumerate(dict.fromkeys(labels))}       # distinct label strings in order of first appearance
+    if len(ids) <= 1:
+        label_id = np.zeros(len(labels), dtype=np.int32)
+    else:
+        label_id = np.fromiter(map(ids.__getitem__, labels), dtype=np.int32, count=len(labels))
     tables = [np.asarray(a, dtype=np.int32) for a in (d_idx, f_mask, f_rowbase, f_nmask, f_flags, view_mask_offs)] + [label_id]
     sizes = [t.size for t in tables]
     tstage = staging.get("tables", 4 * sum(sizes) + 8 * inv.size + 64).numpy()
@@ -268,6 +271,16 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
         n_rows=row, run_start=run_start, run_end=run_end, mask_run_offs=run_offs, view_mask_offs=vmo_d, conf=conf_d,
         labels=labels, label_id=label_d, n_label_ids=max(1, len(ids)), stage1=getattr(scene, "stage1", None),
         unsort=unsort[:n] if sort else None, perm=perm if sort else None, depth_raw=raw_keep, depth_size=raw_size)
+
+
+def _viewed_ids_cached(scene, ratio):
+    """scene.viewed_frame_ids (a sort of the ~3000 colour file names by their number) once per scene object."""
+    cache = scene.__dict__.setdefault("_viewed_ids", {})
+    key = (int(ratio), len(scene.color_files))
+    v = cache.get(key)
+    if v is None:
+        v = cache[key] = viewed_frame_ids(scene.color_files, ratio)
+    return v
 
 
 _taps = {}
