@@ -7,6 +7,8 @@
 // Row norms are accumulated from the same fragments.
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace bff {
@@ -276,6 +278,81 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_tile64_kernel(const _Floa
     }
 }
 
+// Bank-stationary form for config 5 (many rows, a bank of 65..256 columns, dim <= 768): wave t of a block keeps the
+// 16-column strip t of the bank IN REGISTERS for the whole k range (dim / 32 fragments of 4 VGPRs: 96 at dim 768) and
+// multiplies it with every 16-row tile of A the block owns; the block's tiles (<= 4 x 24 KB) are brought into LDS by all
+// its threads in ONE round of loads issued together with the strip's, so the kernel pays one memory latency, not one
+// per k-step (the LDS-staged kernel above: 24 steps x ~1 us of exposed load latency on 141 CUs).  A is read from HBM
+// once, the bank 256 x out of L2, every MFMA's A fragment comes out of LDS (16 B per lane), its B fragment is already
+// there.  One block per CU (13 waves at config 5), tiles dealt round-robin.
+constexpr int kBankSteps = 24;                                // k-steps held in registers: dim <= 768
+constexpr int kBankTiles = 4;                                 // 16-row tiles of A resident in LDS per round
+constexpr int kAPitch = 768 + 8;                              // halves per staged row (+16 B: rows spread over the banks)
+
+__global__ __launch_bounds__(1024) void cosine_gemm_f16_bank_kernel(const _Float16 *__restrict__ a, int na,
+                                                                     const _Float16 *__restrict__ b, int nb, int dim,
+                                                                     float *__restrict__ out, int norm_b, int n_tiles)
+{
+    extern __shared__ _Float16 sA[];                           // [kBankTiles][16][kAPitch]
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;                  // fragment: row/col r, k = 8*kq .. 8*kq+7
+    const int steps = dim / 32;
+    const int j = wave * 16 + r;                               // this lane's bank column
+    const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    // the strip: all k-steps in flight at once
+    half8 fb[kBankSteps];
+    const _Float16 *b_row = b + (int64_t)(j < nb ? j : 0) * dim + 8 * kq;
+#pragma unroll
+    for (int st = 0; st < kBankSteps; ++st) fb[st] = (j < nb && st < steps) ? *reinterpret_cast<const half8 *>(b_row + 32 * st) : zero;
+    const int pieces_per_row = dim / 8;                       // 16-byte pieces
+    for (int t0 = blockIdx.x; t0 < n_tiles; t0 += gridDim.x * kBankTiles) {       // block-uniform rounds
+        // this round's tiles: t0, t0 + G, t0 + 2 G, t0 + 3 G -> LDS, every thread's pieces in flight together
+        int n_here = 0;
+#pragma unroll
+        for (int q = 0; q < kBankTiles; ++q) n_here += (t0 + q * (int)gridDim.x < n_tiles) ? 1 : 0;
+        const int total = n_here * 16 * pieces_per_row;
+        for (int p = tid; p < total; p += blockDim.x) {
+            const int tl = p / (16 * pieces_per_row), rem = p % (16 * pieces_per_row);
+            const int row = rem / pieces_per_row, piece = rem % pieces_per_row;
+            const int i = (t0 + tl * (int)gridDim.x) * 16 + row;
+            const half8 v = i < na ? *reinterpret_cast<const half8 *>(a + (int64_t)i * dim + 8 * piece) : zero;
+            *reinterpret_cast<half8 *>(&sA[((size_t)tl * 16 + row) * kAPitch + 8 * piece]) = v;
+        }
+        __syncthreads();
+        float sb = 0.f;
+        if (norm_b) {
+#pragma unroll
+            for (int st = 0; st < kBankSteps; ++st) sb = sumsq8(fb[st], sb);
+            sb += __shfl_xor(sb, 16); sb += __shfl_xor(sb, 32);
+        }
+        const float nbj = norm_b ? sqrtf(sb) : 1.0f;
+        for (int tl = 0; tl < n_here; ++tl) {
+            const _Float16 *arow = &sA[((size_t)tl * 16 + r) * kAPitch + 8 * kq];
+            float4v acc = {0.f, 0.f, 0.f, 0.f};
+            float sa = 0.f;
+#pragma unroll
+            for (int st = 0; st < kBankSteps; ++st) {
+                if (st < steps) {                              // wave-uniform
+                    const half8 fa = *reinterpret_cast<const half8 *>(arow + 32 * st);
+                    sa = sumsq8(fa, sa);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[st], acc, 0, 0, 0);
+                }
+            }
+            sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);       // the four k-quarters of a row: lanes r, r+16, r+32, r+48
+            const int i0 = (t0 + tl * (int)gridDim.x) * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = kq * 4 + q;                    // C/D map: col = lane & 15, row = 4*(lane>>4) + q
+                const float nai = sqrtf(__shfl(sa, row));
+                const int i = i0 + row;
+                if (i < na && j < nb) out[(int64_t)i * nb + j] = acc[q] / (nai * nbj);
+            }
+        }
+        __syncthreads();                                       // the next round overwrites the tiles
+    }
+    (void)n_waves;
+}
+
 // Cosine of every (a_i, b_j) pair IN THE DTYPE OF THE EMBEDDINGS, i.e. with the roundings of the reference's
 // tensor expression  (e1 @ e2.T) / (e1.norm() * e2.norm().T)  (compute_clip_similarity R:109-114): each of the
 // four tensor ops rounds its result to the embedding dtype.  The class threshold of the refinement is an order
@@ -318,6 +395,12 @@ __global__ __launch_bounds__(256) void cosine_rows_kernel(const T *__restrict__ 
 
 using namespace bff;
 
+static bool bank_kernel_on()
+{
+    static const bool on = [] { const char *e = getenv("BFF_GEMM_BANK"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 static int launch_cosine_gemm(const void *a, int32_t na, const void *b, int32_t nb, int32_t dim, float *cos, int norm_b,
                               void *stream, const char *what)
 {
@@ -325,6 +408,24 @@ static int launch_cosine_gemm(const void *a, int32_t na, const void *b, int32_t 
     BFF_REQUIRE(dim % 32 == 0, "%s: dim must be a multiple of 32", what);
     if (na == 0 || nb == 0) return BFF_OK;
     BFF_REQUIRE(a && b && cos, "%s: null pointer", what);
+    if (nb > 64 && nb <= 256 && na >= 2048 && dim <= 32 * kBankSteps && bank_kernel_on()) {
+        // many rows against a bank of <= 256 columns: the bank stays in registers, A streams through LDS once
+        const int n_ct = (int)ceil_div(nb, 16), n_tiles = (int)ceil_div(na, 16);
+        const size_t lds = sizeof(_Float16) * (size_t)kBankTiles * 16 * kAPitch;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_gemm_f16_bank_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail((int)e, "%s: LDS attribute: %s", what, hipGetErrorString(e));
+            attr_set = true;
+        }
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        const int grid = n_tiles < cus ? n_tiles : cus;
+        cosine_gemm_f16_bank_kernel<<<grid, 64 * n_ct, lds, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b, nb,
+                                                                              dim, cos, norm_b, n_tiles);
+        return launched(what);
+    }
     if (nb > 64 && na >= 2048) {                               // many rows, wide bank: the bank's k-slices through LDS
         cosine_gemm_f16_tile64_kernel<<<(unsigned)ceil_div(na, 64), 256, 0, as_stream(stream)>>>(
             (const _Float16 *)a, na, (const _Float16 *)b, nb, dim, cos, norm_b);

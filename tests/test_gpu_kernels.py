@@ -783,6 +783,24 @@ def test_cosine_golden_on_device(lib):
     assert (sub32 - ref[:50]).abs().max().item() <= 5e-7
 
 
+@pytest.mark.parametrize("na,nb,dim", [(9000, 200, 768), (20_001, 198, 768), (3000, 70, 512), (2049, 256, 32), (2048, 65, 736)])
+def test_cosine_gemm_bank_stationary_shapes(lib, na, nb, dim, monkeypatch):
+    """The bank-stationary MFMA kernel (bank strips in registers, A through LDS once; config 5's shape) on ragged row /
+    column counts, several rounds of row tiles (na > 4 x CUs x 16), short k ranges: within north_star's 1e-4 of the
+    float64 cosine, and equal to the LDS-staged kernel it replaces up to float32 summation order."""
+    gen = torch.Generator().manual_seed(na + nb)
+    a = torch.randn(na, dim, generator=gen).half().to(DEV)
+    b = torch.randn(nb, dim, generator=gen).half().to(DEV)
+    got = lib.cosine_gemm_f16(a, b).cpu().double()
+    ad, bd = a.cpu().double(), b.cpu().double()
+    ref = (ad @ bd.T) / (ad.norm(dim=1, keepdim=True) * bd.norm(dim=1, keepdim=True).T)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() <= 1e-4
+    raw = lib.normalized_gemm_f16(a, b).cpu().double() if hasattr(lib, "normalized_gemm_f16") else None
+    if raw is not None:                                       # bank rows taken as already normalised: a / |a| . b
+        ref2 = (ad / ad.norm(dim=1, keepdim=True)) @ bd.T
+        assert (raw - ref2).abs().max().item() <= 1e-4 * bd.norm(dim=1).max().item()
+
+
 @pytest.mark.parametrize("thr", [-1.0, -0.5, 0.0])
 def test_components_negative_threshold_with_empty_tiles(lib, thr):
     """iou_thres < 0: an empty row (IoU 0 with any non-empty row of its label, NaN with another empty row) joins
