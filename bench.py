@@ -224,14 +224,13 @@ def bench_cosine(args):
         "unit": "gemms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": "c5: 9000 x 768 f16 features against a 200 x 768 f16 bank, f32 accumulate + normalise"},
-        "roofline": {"bound": "mfma", "kernel": "cosine_gemm_f16_kernel", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": "cosine_gemm_f16_bank_kernel", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None,
-                     "note": "2.8 GFLOP per launch (SURVEY section 8d).  One block per 64 rows of A, a wave per 16 rows against all "
-                             "13 column tiles; the bank's 32-k slices are staged once per block in LDS (double buffered, next slice "
-                             "in registers while the current one is multiplied); A is read once, the bank 141 times out of L2.  141 "
-                             "blocks on 256 CUs, one block per CU: the step time (1.1 us per 32 k) follows the bytes staged per "
-                             "block, not MFMA issue (13 MFMAs = 0.1-0.2 us).  Earlier forms: one wave per 16x16 tile 52-60 us "
-                             "(A re-read per column tile), k split over a block's waves 45 us"},
+                     "note": "2.8 GFLOP per launch (SURVEY section 8d).  Bank-stationary kernel: one block per CU, wave t keeps the 16-column "
+                             "strip t of the bank in registers for the whole k range (96 VGPRs), the block's 16-row tiles of A go through "
+                             "LDS once; A is read from HBM once.  Measured split of the launch (parts switched off): empty shell 6.4 us, A "
+                             "0.5 us, bank strips 7 us (16 half lines per load instruction), LDS fragment reads + MFMAs 6.4 us, 7.2 MB of "
+                             "results 3.7 us.  Earlier forms: LDS-staged bank slices 26.4 us, one wave per 16x16 tile 52-60 us"},
         "max_abs_err_vs_f64": err}))
 
 

@@ -278,65 +278,94 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_tile64_kernel(const _Floa
     }
 }
 
-// Bank-stationary form for config 5 (many rows, a bank of 65..256 columns, dim <= 768): wave t of a block keeps the
+// Bank-stationary form for config 5 (many rows, a bank of 65..256 columns, dim = 768 (CLIP ViT-L/14) or 512 (ViT-B/32)): wave t of a block keeps the
 // 16-column strip t of the bank IN REGISTERS for the whole k range (dim / 32 fragments of 4 VGPRs: 96 at dim 768) and
 // multiplies it with every 16-row tile of A the block owns; the block's tiles (<= 4 x 24 KB) are brought into LDS by all
 // its threads in ONE round of loads issued together with the strip's, so the kernel pays one memory latency, not one
 // per k-step (the LDS-staged kernel above: 24 steps x ~1 us of exposed load latency on 141 CUs).  A is read from HBM
 // once, the bank 256 x out of L2, every MFMA's A fragment comes out of LDS (16 B per lane), its B fragment is already
 // there.  One block per CU (13 waves at config 5), tiles dealt round-robin.
-constexpr int kBankSteps = 24;                                // k-steps held in registers: dim <= 768
+// Measured at 9000 x 200 x 768 (kernel with parts switched off, 200 launches back to back): 23.7 us in all = 6.4 us of an
+// empty shell (launch of 256 x 832 threads with 99 KB of LDS, staging loop, epilogue arithmetic) + 0.5 us for A (13.8 MB
+// from HBM, hidden under the strip's loads) + 7 us for the bank strips (every lane's 24 fragments are 64 B apart: a load
+// instruction touches 16 half lines; the same 24 KB read as 1-KB contiguous loads cost 2.5 us -- an LDS transpose of the
+// strip would buy ~4 us) + 6.4 us for 72 LDS fragment reads + MFMAs per wave (LDS-read bound: 16 B per lane and MFMA)
+// + 3.7 us for the 7.2 MB of results (64-B row segments).
 constexpr int kBankTiles = 4;                                 // 16-row tiles of A resident in LDS per round
-constexpr int kAPitch = 768 + 8;                              // halves per staged row (+16 B: rows spread over the banks)
+constexpr int kAPitch = 768 + 8;                              // (also used at dim 512)                              // halves per staged row (+16 B: rows spread over the banks)
 
+template <int kDim, int kStage>
 __global__ __launch_bounds__(1024) void cosine_gemm_f16_bank_kernel(const _Float16 *__restrict__ a, int na,
-                                                                     const _Float16 *__restrict__ b, int nb, int dim,
+                                                                     const _Float16 *__restrict__ b, int nb,
                                                                      float *__restrict__ out, int norm_b, int n_tiles)
 {
+    constexpr int dim = kDim;
     extern __shared__ _Float16 sA[];                           // [kBankTiles][16][kAPitch]
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6, n_waves = blockDim.x >> 6;
     const int r = lane & 15, kq = lane >> 4;                  // fragment: row/col r, k = 8*kq .. 8*kq+7
-    const int steps = dim / 32;
+    constexpr int steps = kDim / 32;
     const int j = wave * 16 + r;                               // this lane's bank column
     const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    // the strip: all k-steps in flight at once
-    half8 fb[kBankSteps];
+    constexpr int pieces_per_row = kDim / 8;                  // 16-byte pieces
+    constexpr int tile_pieces = 16 * pieces_per_row;
+    // a round = up to kBankTiles of the block's tiles (what the LDS holds), fetched kStage pieces per thread at a time
+    // (config 5: 13 waves, 3 tiles -> two batches; the registers of a batch are free again once it sits in LDS)
+    const int round_tiles = kBankTiles;
+    // the strip: all k-steps in flight at once, together with the first batch of A pieces below
+    half8 fb[steps];
     const _Float16 *b_row = b + (int64_t)(j < nb ? j : 0) * dim + 8 * kq;
 #pragma unroll
-    for (int st = 0; st < kBankSteps; ++st) fb[st] = (j < nb && st < steps) ? *reinterpret_cast<const half8 *>(b_row + 32 * st) : zero;
-    const int pieces_per_row = dim / 8;                       // 16-byte pieces
-    for (int t0 = blockIdx.x; t0 < n_tiles; t0 += gridDim.x * kBankTiles) {       // block-uniform rounds
-        // this round's tiles: t0, t0 + G, t0 + 2 G, t0 + 3 G -> LDS, every thread's pieces in flight together
+    for (int st = 0; st < steps; ++st) fb[st] = j < nb ? *reinterpret_cast<const half8 *>(b_row + 32 * st) : zero;
+    for (int t0 = blockIdx.x; t0 < n_tiles; t0 += gridDim.x * round_tiles) {       // block-uniform rounds
+        // this round's tiles: t0, t0 + G, ... -> registers (every piece of a thread in flight together; in the first round
+        // the bank strip's fragments with them) -> LDS
         int n_here = 0;
+        for (int q = 0; q < round_tiles; ++q) n_here += (t0 + q * (int)gridDim.x < n_tiles) ? 1 : 0;
+        const int total = n_here * tile_pieces;
+        half8 piece[kStage];
+        const int reps = (total + kStage * (int)blockDim.x - 1) / (kStage * (int)blockDim.x);
+        for (int rep = 0; rep < reps; ++rep) {
 #pragma unroll
-        for (int q = 0; q < kBankTiles; ++q) n_here += (t0 + q * (int)gridDim.x < n_tiles) ? 1 : 0;
-        const int total = n_here * 16 * pieces_per_row;
-        for (int p = tid; p < total; p += blockDim.x) {
-            const int tl = p / (16 * pieces_per_row), rem = p % (16 * pieces_per_row);
-            const int row = rem / pieces_per_row, piece = rem % pieces_per_row;
-            const int i = (t0 + tl * (int)gridDim.x) * 16 + row;
-            const half8 v = i < na ? *reinterpret_cast<const half8 *>(a + (int64_t)i * dim + 8 * piece) : zero;
-            *reinterpret_cast<half8 *>(&sA[((size_t)tl * 16 + row) * kAPitch + 8 * piece]) = v;
+            for (int q = 0; q < kStage; ++q) {
+                const int p = tid + (int)blockDim.x * (q + kStage * rep);
+                piece[q] = zero;
+                if (p < total) {
+                    const int tl = p / tile_pieces, rem = p - tl * tile_pieces;
+                    const int row = rem / pieces_per_row, pc = rem - row * pieces_per_row;
+                    const int i = (t0 + tl * (int)gridDim.x) * 16 + row;
+                    if (i < na) piece[q] = *reinterpret_cast<const half8 *>(a + (int64_t)i * dim + 8 * pc);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kStage; ++q) {
+                const int p = tid + (int)blockDim.x * (q + kStage * rep);
+                if (p < total) {
+                    const int tl = p / tile_pieces, rem = p - tl * tile_pieces;
+                    const int row = rem / pieces_per_row, pc = rem - row * pieces_per_row;
+                    *reinterpret_cast<half8 *>(&sA[((size_t)tl * 16 + row) * kAPitch + 8 * pc]) = piece[q];
+                }
+            }
         }
         __syncthreads();
         float sb = 0.f;
         if (norm_b) {
 #pragma unroll
-            for (int st = 0; st < kBankSteps; ++st) sb = sumsq8(fb[st], sb);
+            for (int st = 0; st < steps; ++st) sb = sumsq8(fb[st], sb);
             sb += __shfl_xor(sb, 16); sb += __shfl_xor(sb, 32);
         }
         const float nbj = norm_b ? sqrtf(sb) : 1.0f;
         for (int tl = 0; tl < n_here; ++tl) {
             const _Float16 *arow = &sA[((size_t)tl * 16 + r) * kAPitch + 8 * kq];
-            float4v acc = {0.f, 0.f, 0.f, 0.f};
+            float4v acc = {0.f, 0.f, 0.f, 0.f};                // one chain: the SIMD's other waves fill the MFMA's latency
             float sa = 0.f;
 #pragma unroll
-            for (int st = 0; st < kBankSteps; ++st) {
-                if (st < steps) {                              // wave-uniform
-                    const half8 fa = *reinterpret_cast<const half8 *>(arow + 32 * st);
-                    sa = sumsq8(fa, sa);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[st], acc, 0, 0, 0);
-                }
+            for (int st = 0; st < steps; ++st) {
+                // four A fragments in flight at a time: left alone the scheduler hoists all 24 LDS reads (96 registers
+                // next to the 96 of the strip) and spills
+                if (st % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+                const half8 fa = *reinterpret_cast<const half8 *>(arow + 32 * st);
+                sa = sumsq8(fa, sa);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[st], acc, 0, 0, 0);
             }
             sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);       // the four k-quarters of a row: lanes r, r+16, r+32, r+48
             const int i0 = (t0 + tl * (int)gridDim.x) * 16;
@@ -408,22 +437,36 @@ static int launch_cosine_gemm(const void *a, int32_t na, const void *b, int32_t 
     BFF_REQUIRE(dim % 32 == 0, "%s: dim must be a multiple of 32", what);
     if (na == 0 || nb == 0) return BFF_OK;
     BFF_REQUIRE(a && b && cos, "%s: null pointer", what);
-    if (nb > 64 && nb <= 256 && na >= 2048 && dim <= 32 * kBankSteps && bank_kernel_on()) {
+    if (nb > 64 && nb <= 256 && na >= 2048 && (dim == 768 || dim == 512) && bank_kernel_on()) {
         // many rows against a bank of <= 256 columns: the bank stays in registers, A streams through LDS once
         const int n_ct = (int)ceil_div(nb, 16), n_tiles = (int)ceil_div(na, 16);
         const size_t lds = sizeof(_Float16) * (size_t)kBankTiles * 16 * kAPitch;
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_gemm_f16_bank_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipSuccess;
+            for (const void *fn : {reinterpret_cast<const void *>(cosine_gemm_f16_bank_kernel<768, 2>),
+                                   reinterpret_cast<const void *>(cosine_gemm_f16_bank_kernel<768, 4>),
+                                   reinterpret_cast<const void *>(cosine_gemm_f16_bank_kernel<512, 4>)})
+                if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail((int)e, "%s: LDS attribute: %s", what, hipGetErrorString(e));
             attr_set = true;
         }
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        static const int cus = [] {                            // once: the query costs microseconds, the kernel ~10
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+            return n;
+        }();
         const int grid = n_tiles < cus ? n_tiles : cus;
-        cosine_gemm_f16_bank_kernel<<<grid, 64 * n_ct, lds, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b, nb,
-                                                                              dim, cos, norm_b, n_tiles);
+        static const int stage = [] { const char *e = getenv("BFF_GEMM_STAGE"); return e ? atoi(e) : 2; }();
+        if (dim == 768 && stage == 2)
+            cosine_gemm_f16_bank_kernel<768, 2><<<grid, 64 * n_ct, lds, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b,
+                                                                                          nb, cos, norm_b, n_tiles);
+        else if (dim == 768)
+            cosine_gemm_f16_bank_kernel<768, 4><<<grid, 64 * n_ct, lds, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b,
+                                                                                          nb, cos, norm_b, n_tiles);
+        else
+            cosine_gemm_f16_bank_kernel<512, 4><<<grid, 64 * n_ct, lds, as_stream(stream)>>>((const _Float16 *)a, na, (const _Float16 *)b,
+                                                                                          nb, cos, norm_b, n_tiles);
         return launched(what);
     }
     if (nb > 64 && na >= 2048) {                               // many rows, wide bank: the bank's k-slices through LDS

@@ -77,6 +77,23 @@ class Staging:
         self.event.record()
 
 
+_TRACE = os.environ.get("BFF_INGEST_TRACE") == "1"
+trace_log = []                 # (phase, seconds) appended by loader threads when BFF_INGEST_TRACE=1 (list.append is atomic)
+
+
+class _Lap:
+    """Phase clock of one prepare_scene_fast call (diagnostic, off unless BFF_INGEST_TRACE=1)."""
+
+    def __init__(self):
+        self.t = time.perf_counter() if _TRACE else 0.0
+
+    def __call__(self, phase):
+        if _TRACE:
+            now = time.perf_counter()
+            trace_log.append((phase, now - self.t))
+            self.t = now
+
+
 def pack_rles(rles, expect_length, staging: Staging, tag, n_threads=4):
     """RLE dicts -> (run_start, run_end, offs) int32 pinned views, or None when the native fast path declines
     (unsorted / overlapping runs etc.: the caller uses scene.runs_from_rles)."""
@@ -107,7 +124,9 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
     if dev.type != "cuda":
         return prepare_scene(scene, cfg, device=device, with_viewed=with_viewed)
     staging = staging or Staging()
+    lap = _Lap()
     staging.wait()                                   # the previous scene's copies out of these buffers are done
+    lap("wait for the staging buffers")
     h, w = int(cfg.height_2d), int(cfg.width_2d)
     pts = np.asarray(scene.points)
     if pts.dtype != np.float64 or pts.ndim != 2 or pts.shape[1] < 3 or not pts.flags.c_contiguous:
@@ -161,8 +180,10 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
         pose_ids.append(fid); d_idx.append(slot(fid)); f_mask.append(-1); f_rowbase.append(0); f_nmask.append(0); f_flags.append(1)
     nf = len(pose_ids)
 
+    lap("frame table (python)")
     # ---- 2-D RLE -> run tables (native threads), straight into pinned staging
     packed = pack_rles(all_rles, h * w, staging, "m2d", n_threads) if all_rles else None
+    lap("run tables (native)")
     if all_rles and packed is None:
         return prepare_scene(scene, cfg, device=device, with_viewed=with_viewed)       # rare inputs: exact slow path
     if packed is None:
@@ -180,6 +201,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
     else:
         inv = np.zeros((0, 16))
 
+    lap("run-table upload + pose inverses")
     # ---- depth: frames packed into pinned staging by native threads, ONE asynchronous copy
     raw_keep = raw_size = None
     raw_depth = getattr(scene, "depths_raw", None)
@@ -214,6 +236,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
     else:
         depth_dev = torch.zeros((0, h * w), dtype=torch.float32, device=dev)
 
+    lap("depth (pack / enqueue / tile)")
     # ---- cloud: upload as stored, sort + lay out on the device
     pstage = staging.get("points", pts.nbytes)
     np.copyto(pstage.numpy()[:pts.nbytes].view(np.float64).reshape(n, stride), pts)
@@ -236,6 +259,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
         xyz.zero_()
     bounds = _lib.point_tile_bounds(xyz, n) if n else None
 
+    lap("cloud (copy to pinned, enqueue, layout)")
     # ---- small tables: one pinned block, one copy
     if conf_list:
         dts = {c.dtype for c in conf_list}
@@ -263,6 +287,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
     inv_d = tdev[at:at + 8 * inv.size].view(torch.float64).view(nf, 16)
     conf_d = conf.pin_memory().to(dev, non_blocking=True) if conf.numel() else conf.to(dev)
     staging.fence()                                  # the pinned buffers may be rewritten once these copies are done
+    lap("small tables")
     return DeviceScene(
         scene_id=scene.scene_id, n_points=n, nw=nw, height=h, width=w,
         cam_intr=np.asarray(scene.cam_intr, dtype=np.float64)[:3, :3].copy(), xyz=xyz, tile_bounds=bounds, depth=depth_dev,
@@ -416,6 +441,16 @@ def bench_host_inclusive(scenes, cfg, device, query, sim, steps=40, n_loaders=4,
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ing.close()
+    if _TRACE:
+        import collections
+        import sys
+        acc = collections.defaultdict(lambda: [0.0, 0])
+        for phase, sec in trace_log:
+            acc[phase][0] += sec
+            acc[phase][1] += 1
+        for phase, (sec, cnt) in acc.items():
+            print(f"ingest trace: {phase:42s} {1e3 * sec / max(cnt, 1):7.3f} ms per call ({cnt} calls)", file=sys.stderr)
+        print(f"ingest trace: whole leg {1e3 * dt / steps:.3f} ms per scene", file=sys.stderr)
     sc = host[0]
     f0 = next(iter(sc.depths_raw.values()))
     depth_bytes = len(sc.depths_raw) * f0.nbytes
