@@ -75,7 +75,7 @@ PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, [
          "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_label_plane_stride": (c_int64, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
          "bff_point_tile_size": (c_int32, []), "bff_depth_tiled_texels": (c_int64, [c_int32, c_int32]), "bff_merge_scratch_words": (c_int64, [c_int32]), "bff_merge_uses_chunk_bound": (c_int32, [c_int64]),
          "bff_profile_next_merge": (c_int32, [_P, _P]), "bff_group_slice_cap": (c_int32, [c_int32, c_int32]),
-         "bff_resolve_overlaps_scratch_words": (c_int64, []), "bff_point_threshold_scratch_words": (c_int64, [c_int64]), "bff_point_threshold_capacity": (c_int32, []), "bff_point_threshold_capacity_set": (c_int32, [c_int32]), "bff_scene_header_words": (c_int32, [c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
+         "bff_resolve_overlaps_scratch_words": (c_int64, []), "bff_point_threshold_scratch_words": (c_int64, [c_int64]), "bff_point_threshold_capacity": (c_int32, []), "bff_point_threshold_capacity_set": (c_int32, [c_int32]), "bff_scene_header_words": (c_int32, [c_int32, c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
          "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
          "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}

@@ -85,8 +85,8 @@ __device__ __forceinline__ void tile_popcount(const uint64_t *__restrict__ a, co
     }
 }
 
-constexpr int kFuseMax = 256;     // rows of the fused overlap pass = groups the device forms by itself
-constexpr int kMW = kFuseMax / 64; // words of one row's pair mask
+constexpr int kFuseMax = BFF_GROUP_CAP_MAX;      // most rows of the fused overlap pass = most groups the device forms by itself
+constexpr int kMW = kFuseMax / 64;               // words of one row's pair mask
 
 __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__restrict__ a,
                                                               const int32_t *__restrict__ ia, int na,
@@ -1731,10 +1731,14 @@ __global__ __launch_bounds__(256) void overlap_masks_kernel(const int32_t *__res
     }
 }
 
-__global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restrict__ rows, int64_t nw, int k,
+// ColT = uint64_t: a block works on 64 word columns (k <= 256 rows: 133 KB of LDS); uint32_t: on 64 HALF-word columns
+// (32 words), which lets twice as many rows fit (k <= 512) -- the pass is bitwise, so halves of words are columns like
+// any other.  The pair masks are wave-uniform and come straight from global memory (scalar loads).
+template <typename ColT>
+__global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restrict__ rows64, int64_t nw, int k,
                                                               const unsigned long long *__restrict__ pmask,
                                                               const int32_t *__restrict__ size,
-                                                              const uint64_t *__restrict__ keep,
+                                                              const uint64_t *__restrict__ keep64,
                                                               int32_t *__restrict__ after,
                                                               const int32_t *__restrict__ k_dev,
                                                               const int32_t *__restrict__ inter, int stride,
@@ -1752,32 +1756,33 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
     if (before && blockIdx.x == 0)
         for (int r = threadIdx.x; r < k; r += kWave) before[r] = inter[(int64_t)r * stride + r];
     constexpr int kPitch = kWave + 1;                        // column- and row-wise LDS accesses both conflict-free
-    __shared__ unsigned long long s_mask[kFuseMax * kMW];    // row i -> rows j > i that overlap it
     __shared__ int s_size[kFuseMax];
     extern __shared__ uint64_t s_dyn[];
-    uint64_t *s_col = s_dyn;                                 // [k][kPitch]
+    ColT *s_col = reinterpret_cast<ColT *>(s_dyn);           // [k][kPitch]
     const int t = threadIdx.x;
+    ColT *rows = reinterpret_cast<ColT *>(rows64);
+    const ColT *keep = reinterpret_cast<const ColT *>(keep64);
+    const int64_t ncol = nw * (int64_t)(sizeof(uint64_t) / sizeof(ColT));      // columns of ColT per row
     const int64_t w = (int64_t)blockIdx.x * kWave + t;
     const int kw = (k + 63) / 64;
-    // independent loads, several in flight: the pair masks, the sizes, then this thread's word of every row
-    for (int q = t; q < k * kMW; q += kWave) s_mask[q] = pmask[q];
+    // independent loads, several in flight: the sizes, then this thread's column of every row
     for (int r = t; r < k; r += kWave) s_size[r] = size[r];
 #pragma unroll 8
-    for (int r = 0; r < k; ++r) s_col[r * kPitch + t] = w < nw ? rows[(int64_t)r * nw + w] : 0;
+    for (int r = 0; r < k; ++r) s_col[r * kPitch + t] = w < ncol ? rows[(int64_t)r * ncol + w] : 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // single wave: its LDS ops complete in order
-    // The reference's ordered pair loop (P:285-299) for this thread's word column.  Row i stays in a register while its
+    // The reference's ordered pair loop (P:285-299) for this thread's column.  Row i stays in a register while its
     // partners j > i are visited; their words are read eight at a time (independent LDS reads, one latency per batch
     // instead of one read-modify-write round trip per pair), updated in registers in the reference's order, and the
     // ones that changed are written back.
     for (int i = 0; i < k; ++i) {
-        uint64_t acc = s_col[i * kPitch + t];
+        ColT acc = s_col[i * kPitch + t];
         const int size_i = s_size[i];
         bool touched = false;
         for (int q = 0; q < kw; ++q) {
-            unsigned long long m = s_mask[i * kMW + q];       // wave-uniform
+            unsigned long long m = pmask[(int64_t)i * kMW + q];       // wave-uniform
             while (m) {
                 int js[8];
-                uint64_t v[8];
+                ColT v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     js[e] = -1;
@@ -1800,17 +1805,17 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
         }
         if (touched) s_col[i * kPitch + t] = acc;
     }
-    const uint64_t kp = keep ? (w < nw ? keep[w] : 0) : ~0ull;
+    const ColT kp = keep ? (w < ncol ? keep[w] : 0) : (ColT)~(ColT)0;
     for (int r = 0; r < k; ++r) {
-        const uint64_t v = s_col[r * kPitch + t] & kp;
+        const ColT v = s_col[r * kPitch + t] & kp;
         s_col[r * kPitch + t] = v;
-        if (w < nw) rows[(int64_t)r * nw + w] = v;
+        if (w < ncol) rows[(int64_t)r * ncol + w] = v;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int r = t; r < k; r += kWave) {                      // lane adds up rows r, r + 64, ... over the block's 64 columns
         int pc = 0;
 #pragma unroll 8
-        for (int c = 0; c < kWave; ++c) pc += popc64(s_col[r * kPitch + c]);
+        for (int c = 0; c < kWave; ++c) pc += popc64((uint64_t)s_col[r * kPitch + c]);
         if (pc) atomicAdd(after + r, pc);
     }
 }
@@ -1970,11 +1975,29 @@ static int resolve_lds_attr(size_t bytes, const char *what)
 {
     static size_t enabled = 0;
     if (bytes <= enabled || bytes <= 64 * 1024) return BFF_OK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resolve_overlaps_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * kFuseMax * (kWave + 1)));
+    constexpr size_t kMost = sizeof(uint64_t) * (kFuseMax / 2) * (kWave + 1);      // 256 rows of words = 512 rows of half words
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resolve_overlaps_kernel<uint64_t>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMost);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resolve_overlaps_kernel<uint32_t>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMost);
     if (e != hipSuccess) return fail((int)e, "%s: LDS attribute: %s", what, hipGetErrorString(e));
-    enabled = sizeof(uint64_t) * kFuseMax * (kWave + 1);
+    enabled = kMost;
     return BFF_OK;
+}
+
+// the fused overlap pass for k rows: word columns up to kFuseMax / 2 rows, half-word columns beyond (see the kernel)
+static void launch_resolve(uint64_t *rows, int64_t nw, int k, const uint64_t *pair_masks, const int32_t *size,
+                           const uint64_t *keep, int32_t *after, const int32_t *k_dev, const int32_t *inter, int stride,
+                           int32_t *before, hipStream_t st)
+{
+    const int64_t nwp = nw > 0 ? nw : 1;
+    if (k <= kFuseMax / 2)
+        resolve_overlaps_kernel<uint64_t><<<(unsigned)ceil_div(nwp, kWave), kWave, sizeof(uint64_t) * (size_t)k * (kWave + 1), st>>>(
+            rows, nw, k, (const unsigned long long *)pair_masks, size, keep, after, k_dev, inter, stride, before);
+    else
+        resolve_overlaps_kernel<uint32_t><<<(unsigned)ceil_div(2 * nwp, kWave), kWave, sizeof(uint32_t) * (size_t)k * (kWave + 1), st>>>(
+            rows, nw, k, (const unsigned long long *)pair_masks, size, keep, after, k_dev, inter, stride, before);
 }
 #define BFF_TRY_LDS(bytes, what) do { const int rc_ = resolve_lds_attr((bytes), (what)); if (rc_ != BFF_OK) return rc_; } while (0)
 
@@ -2324,10 +2347,8 @@ extern "C" int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const
     if (e != hipSuccess) return fail((int)e, "bff_resolve_overlaps: memset: %s", hipGetErrorString(e));
     overlap_masks_kernel<<<(unsigned)ceil_div(k, 4), 256, 0, as_stream(stream)>>>(inter, k, k, nullptr,
                                                                                 (unsigned long long *)pair_masks, before);
-    BFF_TRY_LDS(sizeof(uint64_t) * (size_t)k * (kWave + 1), "bff_resolve_overlaps");
-    resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave, sizeof(uint64_t) * (size_t)k * (kWave + 1),
-                              as_stream(stream)>>>(rows, nw, k, (const unsigned long long *)pair_masks, size, keep, after, nullptr,
-                                                   nullptr, 0, nullptr);
+    BFF_TRY_LDS((k <= kFuseMax / 2 ? sizeof(uint64_t) : sizeof(uint32_t)) * (size_t)k * (kWave + 1), "bff_resolve_overlaps");
+    launch_resolve(rows, nw, k, pair_masks, size, keep, after, nullptr, nullptr, 0, nullptr, as_stream(stream));
     return launched("bff_resolve_overlaps");
 }
 
@@ -2343,10 +2364,9 @@ extern "C" int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t n
     if (!masks_ready)           // masks_ready: bff_cross_popcount_dev(..., pair_masks) built them with the intersections
         overlap_masks_kernel<<<(unsigned)ceil_div(k_cap, 4), 256, 0, as_stream(stream)>>>(inter, k_cap, k_cap, k_dev,
                                                                                         (unsigned long long *)pair_masks, before);
-    BFF_TRY_LDS(sizeof(uint64_t) * (size_t)k_cap * (kWave + 1), "bff_resolve_overlaps_dev");
-    resolve_overlaps_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), kWave, sizeof(uint64_t) * (size_t)k_cap * (kWave + 1),
-                              as_stream(stream)>>>(rows, nw, k_cap, (const unsigned long long *)pair_masks, size, keep, after, k_dev,
-                                                   inter, k_cap, masks_ready ? before : nullptr);
+    BFF_TRY_LDS((k_cap <= kFuseMax / 2 ? sizeof(uint64_t) : sizeof(uint32_t)) * (size_t)k_cap * (kWave + 1), "bff_resolve_overlaps_dev");
+    launch_resolve(rows, nw, k_cap, pair_masks, size, keep, after, k_dev, inter, k_cap, masks_ready ? before : nullptr,
+                   as_stream(stream));
     return launched("bff_resolve_overlaps_dev");
 }
 

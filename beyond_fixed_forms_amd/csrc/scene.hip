@@ -31,9 +31,9 @@ int bits_for(int n)
 
 #define BFF_TRY(call) do { const int rc_ = (call); if (rc_ != BFF_OK) return rc_; } while (0)
 
-extern "C" int32_t bff_scene_header_words(int32_t s1_rows)
+extern "C" int32_t bff_scene_header_words(int32_t s1_rows, int32_t cap)
 {
-    return BFF_HDR_CROSS + s1_rows * (BFF_GROUP_CAP + s1_rows);
+    return BFF_HDR_CROSS(cap) + s1_rows * (cap + s1_rows);
 }
 
 extern "C" int32_t bff_scene_struct_bytes(int32_t which)
@@ -51,7 +51,8 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     BFF_REQUIRE(ws->hdr && ws->hdr_host, "bff_scene_project: no header buffers");
     hipStream_t st = as_stream(stream);
     const int64_t n = sc->n_points, nw = sc->nw, hw = (int64_t)sc->height * sc->width;
-    const int n_rows = sc->n_rows, cap = BFF_GROUP_CAP;
+    const int n_rows = sc->n_rows, cap = ws->group_cap;
+    BFF_REQUIRE(cap == BFF_GROUP_CAP || cap == BFF_GROUP_CAP_MAX, "bff_scene_project: group_cap must be %d or %d", BFF_GROUP_CAP, BFF_GROUP_CAP_MAX);
     const int mw = bff_chunk_mask_words(nw);
     int32_t *hdr = ws->hdr;
     hipError_t e;
@@ -73,7 +74,7 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
         BFF_REQUIRE(inside(ws->masked, sizeof(int32_t) * (size_t)n) && inside(ws->viewed, sizeof(int32_t) * (size_t)n) &&
                     inside(ws->count, sizeof(int32_t) * (size_t)n_rows) &&
                     inside(ws->chunk_mask, sizeof(uint64_t) * (size_t)n_rows * mw) && inside(ws->segmap, seg_bytes) &&
-                    inside(hdr, sizeof(int32_t) * (size_t)bff_scene_header_words(sc->s1_rows)) &&
+                    inside(hdr, sizeof(int32_t) * (size_t)bff_scene_header_words(sc->s1_rows, cap)) &&
                     inside(ws->inter, sizeof(int32_t) * (size_t)cap * cap) && inside(ws->agg, sizeof(uint64_t) * (size_t)cap * nw) &&
                     inside(ws->merge_scratch, sizeof(uint32_t) * (size_t)bff_merge_scratch_words(n_rows)) &&
                     inside(ws->pair_masks, sizeof(uint64_t) * (size_t)bff_resolve_overlaps_scratch_words()) &&
@@ -141,17 +142,17 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     // P:203-226 on the device: groups, OR of the members, sequential confidence means
     int32_t *info = hdr + BFF_HDR_K;
     BFF_TRY(bff_group_components(ws->comp, ws->parent, ws->area, n_rows, pr->iou_thres, pr->min_members, cap, ws->count, 1, info,
-                                 hdr + BFF_HDR_SIZES, hdr + BFF_HDR_FIRST, ws->goffs, ws->gmembers, ws->slices, stream));
+                                 hdr + BFF_HDR_SIZES(cap), hdr + BFF_HDR_FIRST(cap), ws->goffs, ws->gmembers, ws->slices, stream));
     BFF_TRY(bff_or_reduce_grouped(ws->rows, nw, n_rows, info, cap, ws->goffs, ws->gmembers, ws->slices, ws->agg, sc->conf,
-                                  sc->conf_f16, hdr + BFF_HDR_CONF, ws->chunk_mask, stream));
+                                  sc->conf_f16, hdr + BFF_HDR_CONF(cap), ws->chunk_mask, stream));
     // last reader of the raw rows is done: give the arena its zeros back -- unless the host has to take the general
     // path (more groups than the device forms), which reads the rows again and clears them itself
     BFF_TRY(bff_clear_flagged_chunks_unless(ws->rows, n_rows, nw, ws->chunk_mask, info + 1, stream));
     // a16 + P:592-596: intersections before any edit (their epilogue leaves the pair flags of P:289-292), ordered
     // overlap decisions, &= keep, both popcounts
     BFF_TRY(bff_cross_popcount_dev(ws->agg, cap, ws->agg, cap, nw, ws->inter, info, 2, cap, ws->pair_masks, stream));
-    BFF_TRY(bff_resolve_overlaps_dev(ws->agg, cap, nw, ws->inter, hdr + BFF_HDR_SIZES, ws->keep, hdr + BFF_HDR_BEFORE,
-                                     hdr + BFF_HDR_AFTER, ws->pair_masks, 1, info, stream));
+    BFF_TRY(bff_resolve_overlaps_dev(ws->agg, cap, nw, ws->inter, hdr + BFF_HDR_SIZES(cap), ws->keep, hdr + BFF_HDR_BEFORE(cap),
+                                     hdr + BFF_HDR_AFTER(cap), ws->pair_masks, 1, info, stream));
     // caller's point order (scatter of the set bits); the refinement's first device pass (R:186-217) rides along when
     // stage 1 is resident.  `both` is the caller's buffer (it outlives the workspace's reuse): its clear is the one
     // fill besides the block's
@@ -165,10 +166,10 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     if (sc->s1_rows > 0) {
         uint64_t *s1 = ws->both + (size_t)cap * nw;
         BFF_TRY(bff_rle_to_rows(sc->s1_run_start, sc->s1_run_end, sc->s1_row_run_offs, sc->s1_rows, n, nw, s1, stream));
-        BFF_TRY(bff_cross_popcount_dev(s1, sc->s1_rows, ws->both, cap + sc->s1_rows, nw, hdr + BFF_HDR_CROSS, info, 0, cap,
+        BFF_TRY(bff_cross_popcount_dev(s1, sc->s1_rows, ws->both, cap + sc->s1_rows, nw, hdr + BFF_HDR_CROSS(cap), info, 0, cap,
                                        nullptr, stream));
     }
-    e = hipMemcpyAsync(ws->hdr_host, hdr, sizeof(int32_t) * (size_t)bff_scene_header_words(sc->s1_rows),
+    e = hipMemcpyAsync(ws->hdr_host, hdr, sizeof(int32_t) * (size_t)bff_scene_header_words(sc->s1_rows, cap),
                        hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return fail((int)e, "bff_scene_project: header copy: %s", hipGetErrorString(e));
     return BFF_OK;

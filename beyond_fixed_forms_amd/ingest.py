@@ -285,7 +285,13 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
     cuts = np.cumsum([0] + sizes)
     d_idx_d, f_mask_d, f_rowbase_d, f_nmask_d, f_flags_d, vmo_d, label_d = (tint[cuts[k]:cuts[k + 1]] for k in range(7))
     inv_d = tdev[at:at + 8 * inv.size].view(torch.float64).view(nf, 16)
-    conf_d = conf.pin_memory().to(dev, non_blocking=True) if conf.numel() else conf.to(dev)
+    if conf.numel():                                 # through the staging too: a pin_memory() per scene is a hipHostMalloc
+        cstage = staging.get("conf", conf.numel() * conf.element_size())
+        cview = cstage[:conf.numel() * conf.element_size()].view(conf.dtype)
+        cview.copy_(conf)
+        conf_d = cview.to(dev, non_blocking=True)
+    else:
+        conf_d = conf.to(dev)
     staging.fence()                                  # the pinned buffers may be rewritten once these copies are done
     lap("small tables")
     return DeviceScene(

@@ -17,9 +17,15 @@ import torch
 
 from . import _lib
 
-GROUP_CAP = 256
+GROUP_CAP = 256            # kept groups the device forms by itself, by default ...
+GROUP_CAP_MAX = 512        # ... and for scenes that were seen to keep more (re-issued once with the larger tables)
 HDR_K, HDR_NUNIQUE, HDR_THR, HDR_OVERFLOW = 0, 4, 5, 6
-HDR_SIZES, HDR_FIRST, HDR_BEFORE, HDR_AFTER, HDR_CONF, HDR_CROSS = (16 + k * GROUP_CAP for k in range(6))
+
+
+def hdr_offsets(cap):
+    """(sizes, first, before, after, conf, cross) word offsets of the header for a workspace with `cap` group slots
+    (BFF_HDR_* of include/bff_hip.h)."""
+    return tuple(16 + k * cap for k in range(6))
 
 
 class SceneStruct(ctypes.Structure):
@@ -49,7 +55,8 @@ _WS_PTRS = ["maskbits", "segmap", "labels", "rows", "chunk_mask", "keep", "tile_
 
 class WorkspaceStruct(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in _WS_PTRS] + [("sort_temp_bytes", c_size_t), ("zero_bytes", c_size_t),
-                                                      ("hdr", c_void_p), ("hdr_host", c_void_p)]
+                                                      ("hdr", c_void_p), ("hdr_host", c_void_p),
+                                                      ("group_cap", c_int32), ("pad_", c_int32)]
 
 
 # Scenes in flight on the device, one HIP stream (and one SceneWorkspace) each.  A scene's device work is a chain of
@@ -176,15 +183,16 @@ class SceneWorkspace:
             return True
         return False
 
-    def fit(self, ds, s1_rows):
-        """Make every buffer large enough for scene `ds` (+ s1_rows stage-1 masks)."""
+    def fit(self, ds, s1_rows, cap=GROUP_CAP):
+        """Make every buffer large enough for scene `ds` (+ s1_rows stage-1 masks) with `cap` group slots."""
         n, nw, n_rows = ds.n_points, ds.nw, ds.n_rows
         hw = ds.height * ds.width
         n_mviews = ds.view_mask_offs.shape[0] - 1
-        key = (n, nw, n_rows, hw, n_mviews, ds.word_bits, s1_rows)
+        key = (n, nw, n_rows, hw, n_mviews, ds.word_bits, s1_rows, cap)
         if key == self._fit_key:                      # same sizes as the last scene on this stream: nothing to check
             return self
         self._fit_key = key
+        self.struct.group_cap = cap
         lib = _lib.load()
         mw = max(lib.bff_chunk_mask_words(nw), 1)
         nt = (n_rows + 63) // 64
@@ -196,12 +204,12 @@ class SceneWorkspace:
         # everything the call's steps expect zeroed lives in ONE allocation, cleared by one fill per scene
         # (bff_scene_workspace): name -> (bytes, dtype of the view)
         seg_words = 2 * n_mviews * _lib.segmap_words(hw)
-        hdr_words = int(lib.bff_scene_header_words(s1_rows))
+        hdr_words = int(lib.bff_scene_header_words(s1_rows, cap))
         use_cpop = bool(lib.bff_merge_uses_chunk_bound(nw))
         parts = [("masked", 4 * n, i32), ("viewed", 4 * n, i32), ("count", 4 * n_rows, i32),
                  ("chunk_mask", 8 * n_rows * mw, i64), ("segmap", 4 * seg_words, i32), ("hdr", 4 * hdr_words, i32),
-                 ("inter", 4 * GROUP_CAP * GROUP_CAP, i32), ("pair_masks", 8 * int(lib.bff_resolve_overlaps_scratch_words()), i64),
-                 ("agg", 8 * GROUP_CAP * nw, i64), ("merge_scratch", 4 * int(lib.bff_merge_scratch_words(n_rows)), i32)]
+                 ("inter", 4 * cap * cap, i32), ("pair_masks", 8 * int(lib.bff_resolve_overlaps_scratch_words()), i64),
+                 ("agg", 8 * cap * nw, i64), ("merge_scratch", 4 * int(lib.bff_merge_scratch_words(n_rows)), i32)]
         if use_cpop:
             parts.append(("chunk_pop", 2 * n_rows * mw * 64, torch.int16))
         offs, at = {}, 0
@@ -225,8 +233,8 @@ class SceneWorkspace:
         self._need("pair_scratch", int(lib.bff_point_threshold_scratch_words(n)), i32)
         for k in ("area", "mean_word", "order", "parent", "comp", "gmembers"):
             self._need(k, n_rows, i32)
-        self._need("goffs", GROUP_CAP + 1, i32)
-        self._need("slices", 3 * lib.bff_group_slice_cap(n_rows, GROUP_CAP), i32)
+        self._need("goffs", cap + 1, i32)
+        self._need("slices", 3 * lib.bff_group_slice_cap(n_rows, cap), i32)
         self._need("vals", n, f32)
         self._need("vals_sorted", n, f32)
         self._need("hist", n_rows * 64, i32)
@@ -261,11 +269,12 @@ def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
         ent = cache[key] = (scene_struct(ds, stage1, n_frames), stage1)      # keeps stage1's tensors alive too
     sc = ent[0]
     s1_rows = int(sc.s1_rows)
-    ws = SceneWorkspace.for_current_stream(dev).fit(ds, s1_rows)
+    cap = int(ds.__dict__.get("_group_cap", GROUP_CAP))           # GROUP_CAP_MAX once the scene was seen to keep more groups
+    ws = SceneWorkspace.for_current_stream(dev).fit(ds, s1_rows, cap)
     if ws.in_flight or ws.rows_dirty:             # a call whose results were never collected: the arena may be dirty
         ws.t["rows"].zero_()
         ws.rows_dirty = False
-    n_both = (GROUP_CAP + s1_rows) * ds.nw
+    n_both = (cap + s1_rows) * ds.nw
     if ws.both_primed < n_both:
         # `both` outlives the workspace's reuse (results are views of it), so it comes from torch's allocator, whose
         # pools are per stream: the first few scenes of a stream would each pay a hipMalloc (~6 ms) until the pool
@@ -273,7 +282,7 @@ def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
         prime = [torch.empty(n_both, dtype=torch.int64, device=dev) for _ in range(4)]
         del prime
         ws.both_primed = n_both
-    both = torch.empty((GROUP_CAP + s1_rows, ds.nw), dtype=torch.int64, device=dev)     # outlives the workspace's reuse
+    both = torch.empty((cap + s1_rows, ds.nw), dtype=torch.int64, device=dev)     # outlives the workspace's reuse
     ws.struct.both = c_void_p(both.data_ptr())
     # the threshold of the point filter: from the set of distinct values (two launches; default) or by a radix sort of all
     # values (12 launches; BFF_FILTER_SORT=1, and automatically for a scene with more distinct values than the set holds)
@@ -286,7 +295,7 @@ def issue(ds, cfg, depth_thresh, stage1=None, n_frames=None):
         import sys
         now = time.perf_counter()
         print(f"slow issue: {1e3 * (now - t0):.2f} ms, of which the native call {1e3 * (now - t1):.2f} ms", file=sys.stderr)
-    return dict(ws=ws, both=both, s1_rows=s1_rows, params=pr, stream=ws.stream,
+    return dict(ws=ws, both=both, s1_rows=s1_rows, params=pr, stream=ws.stream, cap=cap,
                 args=(ds, cfg, depth_thresh, stage1, n_frames))
 
 
@@ -296,9 +305,21 @@ def collect(h):
     h["stream"].synchronize()
     _lib.sync_wait_s += time.perf_counter() - t0
     ws = h["ws"]
-    words = HDR_CROSS + h["s1_rows"] * (GROUP_CAP + h["s1_rows"])
+    cap = h["cap"]
+    words = hdr_offsets(cap)[5] + h["s1_rows"] * (cap + h["s1_rows"])
     hdr = ws.hdr_host.numpy()[:words].copy()
     ws.in_flight = False
+    if (hdr[HDR_K + 1] & 1) and cap < GROUP_CAP_MAX and hdr[HDR_K] <= GROUP_CAP_MAX and hdr[HDR_OVERFLOW] == 0 \
+            and os.environ.get("BFF_GROUP_CAP_FIXED") != "1":
+        # more kept groups than the default tables hold, but within the large ones: run the scene again with those (and
+        # remember it for this scene) -- the general host path costs more than a second call
+        ds = h["args"][0]
+        ds.__dict__["_group_cap"] = GROUP_CAP_MAX
+        ws.rows_dirty = True                      # flags != 0: the call left the raw rows for the host
+        with torch.cuda.stream(h["stream"]):
+            h2 = issue(*h["args"])
+        h.update(h2)
+        return collect(h)
     if hdr[HDR_OVERFLOW] != 0 and not h["params"].filter_sort:
         # more distinct filter values than the pair formulation holds: everything after the sweep is void.  Run the
         # scene again with the sorting formulation (and remember it for this scene).

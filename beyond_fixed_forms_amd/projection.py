@@ -300,12 +300,13 @@ class _WsRows:
 
 
 def _fast_back(fr: _Front, stage1, want_groups) -> Stage2Result:
-    from .pipeline import (GROUP_CAP, HDR_AFTER, HDR_BEFORE, HDR_CONF, HDR_CROSS, HDR_FIRST, HDR_K, HDR_NUNIQUE,
-                           HDR_SIZES, HDR_THR)
+    from .pipeline import HDR_K, HDR_NUNIQUE, HDR_THR, hdr_offsets
     ds, cfg, dbg = fr.ds, fr.cfg, fr.dbg
     h = fr.fast
     hdr = pipeline.collect(h)                                        # the one synchronisation of the scene
     ws, both, s1_rows = h["ws"], h["both"], h["s1_rows"]             # (after it: a re-issued scene has a new `both`)
+    GROUP_CAP = h["cap"]
+    HDR_SIZES, HDR_FIRST, HDR_BEFORE, HDR_AFTER, HDR_CONF, HDR_CROSS = hdr_offsets(GROUP_CAP)
     dev = ds.xyz.device
     n, nw = ds.n_points, ds.nw
     k_all, flags = int(hdr[HDR_K]), int(hdr[HDR_K + 1])

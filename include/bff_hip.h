@@ -440,7 +440,8 @@ int bff_cosine_rows(const void *a, int32_t na, const void *b, int32_t nb, int32_
 /* ------------------------------------------------------------------------------------------
  * Groups formed on the device (P:203-226 without the host round trip) and the whole scene in one call.
  */
-#define BFF_GROUP_CAP 256         /* groups the device forms by itself (= rows of the fused overlap pass) */
+#define BFF_GROUP_CAP 256         /* groups the device forms by itself (= rows of the fused overlap pass): the default ... */
+#define BFF_GROUP_CAP_MAX 512     /* ... and the largest capacity a workspace may ask for (bff_scene_workspace.group_cap) */
 #define BFF_SIGNATURE_BITS 30     /* bff_row_stats signatures are 30-bit keys */
 
 /* Device twin of bff_host_component_csr for at most `cap` <= BFF_GROUP_CAP kept groups.  comp[i] = smallest row index
@@ -473,8 +474,8 @@ int bff_scatter_bits(const uint64_t *rows_in, int32_t n_rows, int64_t nw_in, con
 /* bff_cross_popcount when only the first *k_dev rows of b's leading `lead` rows (and of a, with limit_a) are
  * non-zero: tiles inside the zero part are skipped; inter is zeroed first.  limit_a == 2: a and b are the same rows and
  * only entries inter[i][j] with j >= i (up to tile granularity) are needed.  pair_masks (optional; a == b, at most
- * BFF_GROUP_CAP rows): also writes the pair flags of solve_overlapping (P:289-292) -- bit j of row i's
- * BFF_GROUP_CAP / 64 words = rows j > i that overlap row i -- for bff_resolve_overlaps_dev(masks_ready = 1). */
+ * BFF_GROUP_CAP_MAX rows): also writes the pair flags of solve_overlapping (P:289-292) -- bit j of row i's
+ * BFF_GROUP_CAP_MAX / 64 words = rows j > i that overlap row i -- for bff_resolve_overlaps_dev(masks_ready = 1). */
 int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint64_t *b, int32_t nb, int64_t nw, int32_t *inter,
                            const int32_t *k_dev, int32_t limit_a, int32_t lead, uint64_t *pair_masks, void *stream);
 /* bff_clear_flagged_chunks unless *veto != 0 (device flag). */
@@ -529,8 +530,11 @@ typedef struct bff_scene_workspace {
     int64_t *sig, *sig_keys, *sig_sorted;
     void *sort_temp; size_t sort_temp_bytes;
     size_t zero_bytes;              /* size of the block that starts at `masked` (see above) */
-    int32_t *hdr;                   /* device, bff_scene_header_words(s1_rows) int32 */
+    int32_t *hdr;                   /* device, bff_scene_header_words(s1_rows, group_cap) int32 */
     int32_t *hdr_host;              /* pinned host mirror of the same size */
+    int32_t group_cap;              /* BFF_GROUP_CAP or BFF_GROUP_CAP_MAX: kept groups formed on the device; agg, inter, both and the
+                                       header are sized by it.  More groups than that: header flag, the host continues */
+    int32_t pad_;
 } bff_scene_workspace;
 
 /* Header layout (int32 words). */
@@ -539,13 +543,14 @@ typedef struct bff_scene_workspace {
 #define BFF_HDR_THR 5               /* float32 threshold */
 #define BFF_HDR_OVERFLOW 6          /* != 0: more distinct filter values than bff_point_threshold_pairs holds: run the
                                        scene again with params.filter_sort = 1 (everything after the sweep is void) */
-#define BFF_HDR_SIZES 16                              /* [cap] members per group */
-#define BFF_HDR_FIRST (16 + BFF_GROUP_CAP)            /* [cap] smallest member of the group */
-#define BFF_HDR_BEFORE (16 + 2 * BFF_GROUP_CAP)       /* [cap] popcount before overlap resolution (P:592) */
-#define BFF_HDR_AFTER (16 + 3 * BFF_GROUP_CAP)        /* [cap] popcount after overlaps + point filter (P:596) */
-#define BFF_HDR_CONF (16 + 4 * BFF_GROUP_CAP)         /* [cap] confidence means, in the confidence dtype, packed */
-#define BFF_HDR_CROSS (16 + 5 * BFF_GROUP_CAP)        /* [s1_rows][cap + s1_rows] stage-1 x (stage-2 groups | stage-1) */
-int32_t bff_scene_header_words(int32_t s1_rows);
+/* cap = the workspace's group_cap (BFF_GROUP_CAP or BFF_GROUP_CAP_MAX) */
+#define BFF_HDR_SIZES(cap) 16                         /* [cap] members per group */
+#define BFF_HDR_FIRST(cap) (16 + (cap))               /* [cap] smallest member of the group */
+#define BFF_HDR_BEFORE(cap) (16 + 2 * (cap))          /* [cap] popcount before overlap resolution (P:592) */
+#define BFF_HDR_AFTER(cap) (16 + 3 * (cap))           /* [cap] popcount after overlaps + point filter (P:596) */
+#define BFF_HDR_CONF(cap) (16 + 4 * (cap))            /* [cap] confidence means, in the confidence dtype, packed */
+#define BFF_HDR_CROSS(cap) (16 + 5 * (cap))           /* [s1_rows][cap + s1_rows] stage-1 x (stage-2 groups | stage-1) */
+int32_t bff_scene_header_words(int32_t s1_rows, int32_t cap);
 int32_t bff_scene_struct_bytes(int32_t which);     /* 0 bff_scene, 1 bff_scene_params, 2 bff_scene_workspace */
 
 /* The whole device side of one scene on `stream`, ending with an asynchronous copy of the header into

@@ -453,12 +453,15 @@ def test_similarity_set_near_ties(api, enc_dtype):
     assert dropped > 0                                                    # the threshold did bite
 
 
-@pytest.mark.parametrize("case", ["more_groups_than_the_device_forms", "hundred_groups", "min_members_0", "many_stage2"])
+@pytest.mark.parametrize("case", ["more_groups_than_the_device_forms", "groups_beyond_the_default_tables", "hundred_groups",
+                                  "min_members_0", "many_stage2"])
 def test_fast_path_and_its_fallbacks(api, case):
     """bff_scene_project (one native call per scene, groups formed on the device) against the oracle and against the
-    step-by-step path: (a) a scene whose merge graph has more kept groups than BFF_GROUP_CAP = 256 -- the device tables
-    are incomplete, the host continues from the components (general path); (a') ~90 groups, handled on the device
-    (pair masks of several words in the fused overlap pass); (b) min_aggragated_masks = 0, where the reference's empty
+    step-by-step path: (a) a scene whose merge graph has more kept groups (552) than BFF_GROUP_CAP_MAX = 512 -- the device
+    tables are incomplete, the host continues from the components (general path); (a') 325 groups: more than the
+    default tables (BFF_GROUP_CAP = 256) hold, so the scene is issued again with the large ones and stays on the one-call
+    path (fused overlap pass on half-word columns); (a'') ~90 groups, handled on the device (pair masks of several
+    words in the fused overlap pass); (b) min_aggragated_masks = 0, where the reference's empty
     components survive the filter (general path too); (c) a scene with many surviving stage-2 instances on the fast
     path.  Stage-2 and final results are bit-identical in all cases."""
     projection, refinement = api
@@ -466,6 +469,8 @@ def test_fast_path_and_its_fallbacks(api, case):
     from beyond_fixed_forms_amd.synthetic import make_scene, make_text_bank
     over = {}
     if case == "more_groups_than_the_device_forms":
+        scene = make_scene("tiny", seed=30, n_labels=90, n_masks=64, n_views=40, cut_masks=False)
+    elif case == "groups_beyond_the_default_tables":
         scene = make_scene("tiny", seed=30, n_labels=50, n_masks=64, n_views=24, cut_masks=False)
     elif case == "hundred_groups":
         scene = make_scene("tiny", seed=30, n_labels=12, n_masks=64, n_views=6, cut_masks=False)
@@ -487,10 +492,12 @@ def test_fast_path_and_its_fallbacks(api, case):
         assert res.debug["path"] == "fast" and exp["ins"].shape[0] >= 5
     elif case == "hundred_groups":
         assert res.debug["path"] == "fast" and 64 < len(dbg["groups"]) <= 256
+    elif case == "groups_beyond_the_default_tables":
+        assert res.debug["path"] == "fast" and 256 < len(dbg["groups"]) <= 512 and ds.__dict__.get("_group_cap") == 512
     else:
         assert res.debug["path"].startswith("general")
         if case == "more_groups_than_the_device_forms":
-            assert len(dbg["groups"]) > 256
+            assert len(dbg["groups"]) > 512
     assert list(res.groups) == list(slow.groups) == dbg["groups"]
     same(res.to_dict(), exp)
     same(slow.to_dict(), exp)
