@@ -282,7 +282,8 @@ def compulsory_traffic(ds, dev):
     line_words = (((hw + 15) // 16 + 31) // 32 + 1) // 2 * 2
     if ds.depth_raw is not None:
         per_frame = ds.depth_raw.shape[1] * (ds.depth_raw.shape[2] if ds.depth_raw.dim() == 3 else 1)
-        line_words = max(line_words, (((per_frame + 63) // 64 + 31) // 32 + 1) // 2 * 2)
+        per_line = 128 // ds.depth_raw.element_size()
+        line_words = max(line_words, (((per_frame + per_line - 1) // per_line + 31) // 32 + 1) // 2 * 2)
     dl = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
     ml = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
     ll = torch.zeros((ds.n_frames, line_words), dtype=torch.int32, device=dev)
@@ -290,7 +291,7 @@ def compulsory_traffic(ds, dev):
     if ds.depth_raw is not None:
         _lib.call("bff_diag_sweep_lines_u16", _lib._ptr(ds.xyz), n, ds.xyz.shape[1], _lib._ptr(ds.inv_pose), ctypes.cast(k, ctypes.c_void_p),
                   ds.n_frames, _lib._ptr(ds.depth_raw), *(ds.depth_size if ds.depth_size is not None else ds.depth_raw.shape[1:3]),
-                  0 if ds.depth_size is None else 1, _lib._ptr(ds.depth_index),
+                  0 if ds.depth_size is None else (2 if ds.depth_raw.dtype == torch.float32 else 1), _lib._ptr(ds.depth_index),
                   ds.height, ds.width, 0.08, _lib._ptr(segmap), ds.word_bits, _lib._ptr(ds.frame_mask), _lib._ptr(dl), _lib._ptr(ml),
                   line_words, _lib._ptr(ll))
     else:
@@ -302,7 +303,7 @@ def compulsory_traffic(ds, dev):
     tiles = (ds.n_frames + 7) // 8
     xyz_bytes, counter_bytes = 24 * n * tiles, 16 * n
     return {"bytes": 128 * (depth_lines + mask_lines + label_lines) + xyz_bytes + counter_bytes,
-            "depth_lines_128B": depth_lines, "depth_format": "u16 source frames" if ds.depth_raw is not None else "f32 (H, W)", "mask_word_lines_128B": mask_lines, "mask_label_lines_128B": label_lines, "xyz_bytes (once per 8-frame tile)": xyz_bytes,
+            "depth_lines_128B": depth_lines, "depth_format": ("sensor-resolution frames, " + str(ds.depth_raw.dtype).replace("torch.", "")) if ds.depth_raw is not None else "f32 (H, W)", "mask_word_lines_128B": mask_lines, "mask_label_lines_128B": label_lines, "xyz_bytes (once per 8-frame tile)": xyz_bytes,
             "counter_bytes": counter_bytes}
 
 
@@ -552,8 +553,9 @@ def main():
                                    f"{ds.n_viewed} viewed frames @{h}x{w}, {m} masks/view (Ins={ds.n_rows}), "
                                    f"stage-1 S1={len(scenes[0].stage1['ins'])}, 198x768 f16 text bank; inputs RESIDENT in "
                                    f"HBM (uploaded before the timed region); depth " +
-                                   (f"as stored (uint16 mm, {'x'.join(str(int(v)) for v in (ds.depth_size or ds.depth_raw.shape[1:3]))}"
-                                    f"{', 8x8-texel tiles' if ds.depth_size else ''}), /1000 + bilinear resize "
+                                   (f"at the sensor's resolution ({'x'.join(str(int(v)) for v in (ds.depth_size or ds.depth_raw.shape[1:3]))}, "
+                                    f"{'float32 metres = uint16 / 1000' if ds.depth_raw.dtype == torch.float32 else 'uint16 mm'}"
+                                    f"{', 8x8-texel tiles' if ds.depth_size else ''}), bilinear resize "
                                     f"per point inside the sweep" if ds.depth_raw is not None else "float32 (H, W)") +
                                    f"; {n_scenes} different scenes rotate through the loop",
                        "scenes_per_step": world, "priming_steps_in_setup": priming,

@@ -24,7 +24,7 @@ SIGNATURES = {
     "bff_rle_to_maskbits": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P],
     "bff_rle_to_labels": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P],
     "bff_project_views": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P],
-    "bff_depth_tile_u16": [_P, _I, _I, _I, _P, _P],
+    "bff_depth_tile_u16": [_P, _I, _I, _I, _P, _I, _P],
     "bff_project_views_u16": [_P, _L, _L, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _D, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P],
     "bff_point_tile_bounds": [_P, _L, _L, _P, _P],
     "bff_popcount_rows": [_P, _P, _I, _L, _P, _P],
@@ -212,14 +212,16 @@ def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, hei
                   depth_size=None):
     """depth: float32 [n_depth][H*W] metres, or int16 [n_depth][hs][ws] (the uint16 millimetres of the PNGs): then
     /1000 + the bilinear resize to (height, width) are evaluated per point inside the sweep (bff_project_views_u16).
-    depth_size = (hs, ws): `depth` is int16 [n_depth][depth_tiled_texels(hs, ws)], frames in 8 x 8 tiles (tile_depth)."""
+    depth_size = (hs, ws): `depth` is [n_depth][depth_tiled_texels(hs, ws)], frames in 8 x 8 tiles (tile_depth): int16
+    (the millimetres) or float32 (metres, already divided by 1000)."""
     k = (c_double * 9)(*[float(v) for v in cam_intr.reshape(-1)])
     n_frames = inv_pose.shape[0]
     nw = (n_points + 63) // 64
-    if depth.dtype == torch.int16:
+    if depth.dtype == torch.int16 or depth_size is not None:
         hs, ws = (depth_size if depth_size is not None else depth.shape[1:3])
+        layout = 0 if depth_size is None else (2 if depth.dtype == f32 else 1)
         head = ("bff_project_views_u16", _ptr(xyz_soa, f64), n_points, xyz_soa.shape[1], _ptr(inv_pose, f64),
-                ctypes.cast(k, c_void_p), n_frames, _ptr(depth, torch.int16), int(hs), int(ws), 0 if depth_size is None else 1)
+                ctypes.cast(k, c_void_p), n_frames, _ptr(depth), int(hs), int(ws), layout)
     else:
         head = ("bff_project_views", _ptr(xyz_soa, f64), n_points, xyz_soa.shape[1], _ptr(inv_pose, f64),
                 ctypes.cast(k, c_void_p), n_frames, _ptr(depth, f32))
@@ -230,12 +232,13 @@ def project_views(xyz_soa, n_points, inv_pose, cam_intr, depth, depth_index, hei
          _ptr(viewed_count, i32), _ptr(tile_bounds, f64))
 
 
-def tile_depth(raw):
-    """int16 [F][hs][ws] (uint16 millimetres as stored) -> [F][tiled texels]: every frame in 8 x 8-texel tiles of 128
-    bytes (bff_depth_tile_u16), the layout the sweep gathers its taps from."""
+def tile_depth(raw, metres=True):
+    """int16 [F][hs][ws] (uint16 millimetres as stored) -> [F][tiled texels]: every frame in 8 x 8-texel tiles
+    (bff_depth_tile_u16), the layout the sweep gathers its taps from; metres: float32 `value / 1000` (P:432-435) instead
+    of the uint16 values, so that the sweep neither converts nor divides."""
     f, hs, ws = raw.shape
-    out = torch.empty((f, int(load().bff_depth_tiled_texels(hs, ws))), dtype=torch.int16, device=raw.device)
-    call("bff_depth_tile_u16", _ptr(raw, torch.int16), f, hs, ws, _ptr(out, torch.int16))
+    out = torch.empty((f, int(load().bff_depth_tiled_texels(hs, ws))), dtype=f32 if metres else torch.int16, device=raw.device)
+    call("bff_depth_tile_u16", _ptr(raw, torch.int16), f, hs, ws, _ptr(out), 1 if metres else 0)
     return out
 
 

@@ -30,13 +30,17 @@ struct Intrinsics { double k[9]; };
 // projects to, with exactly the float32 operations of depth_resize_kernel (filter.hip) / io.resize_bilinear_f32 -- the
 // (H, W) float image (8x the bytes of the source) is never built.  hs == H and ws == W: the resize is the identity.
 struct RawDepth {
-    int hs, ws;                 // source size
-    int tw;                     // > 0: frames are stored in 8 x 8-texel tiles of 128 bytes, tw tiles per tile row
-                                // (bff_depth_tile_u16): texel (y, x) sits at ((y >> 3) * tw + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7)
+    const uint32_t *taps;       // device table of the resize, 3 words per destination column then per destination row:
+                                //   column u: (texel offset of its left tap inside a source row, of its right tap, fraction bits)
+                                //   row v:    (texel offset of its upper source row, of its lower one, fraction bits)
+                                // a tap's texel = row offset + column offset; offsets follow the frames' layout (row-major,
+                                // or 8 x 8-texel tiles: ((y >> 3) * tw + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7)); fractions and
+                                // tap indices as io._axis_taps (sensor_taps_kernel below)
+    int n_taps;                 // W + H
+    int texel_f32;              // frames hold float32 metres (`astype(f32) / 1000` done once per texel at ingestion) instead of
+                                // the uint16 millimetres themselves
     int64_t frame_stride;       // texels per frame (padded to whole tiles when tiled)
-    int same;                   // source size == (H, W)
     float scale;                // 1000
-    double sx, sy;              // 1 / (W / ws), 1 / (H / hs) in float64, as io._axis_taps computes them
 };
 
 // io._axis_taps for one destination index: f = (float)((d + 0.5) * scale - 0.5) (float64 products and differences, each
@@ -60,19 +64,43 @@ __device__ __forceinline__ void axis_tap(int d, double scale, int n_src, int &i0
     }
 }
 
-__device__ __forceinline__ int64_t raw_texel(const RawDepth &r, int y, int x)
+// the table RawDepth::taps points to, for source frames of hs x ws texels resized to H x W (tiled != 0: tile layout)
+__global__ void sensor_taps_kernel(int hs, int ws, int H, int W, int tiled, double sx, double sy, uint32_t *__restrict__ table)
 {
-    return r.tw ? ((int64_t)(y >> 3) * r.tw + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7) : (int64_t)y * r.ws + x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W + H) return;
+    const int tw = (ws + 7) / 8;
+    int i0, i1;
+    float a;
+    uint32_t p0, p1;
+    if (i < W) {
+        axis_tap<true>(i, sx, ws, i0, i1, a);
+        p0 = tiled ? (uint32_t)((i0 >> 3) * 64 + (i0 & 7)) : (uint32_t)i0;
+        p1 = tiled ? (uint32_t)((i1 >> 3) * 64 + (i1 & 7)) : (uint32_t)i1;
+    } else {
+        axis_tap<false>(i - W, sy, hs, i0, i1, a);
+        p0 = tiled ? (uint32_t)((i0 >> 3) * tw * 64 + (i0 & 7) * 8) : (uint32_t)(i0 * ws);
+        p1 = tiled ? (uint32_t)((i1 >> 3) * tw * 64 + (i1 & 7) * 8) : (uint32_t)(i1 * ws);
+    }
+    table[3 * i] = p0;
+    table[3 * i + 1] = p1;
+    table[3 * i + 2] = __float_as_uint(a);
 }
 
 // the resized depth value at one pixel from its four source texels (same operation order as depth_resize_kernel)
-__device__ __forceinline__ float bilinear_depth(uint16_t t00, uint16_t t01, uint16_t t10, uint16_t t11, float a, float b,
-                                                float scale)
+__device__ __forceinline__ float bilinear_depth(float s00, float s01, float s10, float s11, float a, float b)
 {
     const float one_a = __fsub_rn(1.0f, a), one_b = __fsub_rn(1.0f, b);
-    const float r0 = __fadd_rn(__fmul_rn(__fdiv_rn((float)t00, scale), one_a), __fmul_rn(__fdiv_rn((float)t01, scale), a));
-    const float r1 = __fadd_rn(__fmul_rn(__fdiv_rn((float)t10, scale), one_a), __fmul_rn(__fdiv_rn((float)t11, scale), a));
+    const float r0 = __fadd_rn(__fmul_rn(s00, one_a), __fmul_rn(s01, a));
+    const float r1 = __fadd_rn(__fmul_rn(s10, one_a), __fmul_rn(s11, a));
     return __fadd_rn(__fmul_rn(r0, one_b), __fmul_rn(r1, b));
+}
+
+// one source texel in metres: float32 frames hold it, uint16 frames hold millimetres (P:432-435: astype(f32) / 1000)
+__device__ __forceinline__ float sensor_texel(const void *frame, uint32_t t, const RawDepth &r)
+{
+    return r.texel_f32 ? reinterpret_cast<const float *>(frame)[t]
+                       : __fdiv_rn((float)reinterpret_cast<const uint16_t *>(frame)[t], r.scale);
 }
 
 __device__ __forceinline__ void lds_phase_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -93,6 +121,12 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
 {
     // per wave: [bit][kPPT words] transposition buffer for the wave's sector of the frame's rows
     __shared__ uint64_t stage_all[kBlock / kWave][sizeof(WordT) * 8][kPPT];
+    extern __shared__ uint32_t s_taps[];                   // kRaw: the resize's tap table (RawDepth::taps), 12 bytes per
+                                                           // destination column / row: two LDS reads replace ~25 instructions
+    if (kRaw) {
+        for (int i = threadIdx.x; i < 3 * raw.n_taps; i += kBlock) s_taps[i] = raw.taps[i];
+        __syncthreads();
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Block -> XCD mapping is the plain round-robin of the dispatch order.  Both XCD-aware mappings were measured on
@@ -167,8 +201,8 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
         if ((culled >> (8 * (f - f0))) & 1) continue;      // wave-uniform
         const double *P = inv_pose + 16 * (int64_t)f;
         const float *dimg = kRaw ? nullptr : reinterpret_cast<const float *>(depth) + (int64_t)depth_index[f] * hw;
-        const uint16_t *rimg = kRaw ? reinterpret_cast<const uint16_t *>(depth) + (int64_t)depth_index[f] * raw.frame_stride
-                                    : nullptr;
+        const char *rimg = kRaw ? reinterpret_cast<const char *>(depth) +
+                                  (int64_t)depth_index[f] * raw.frame_stride * (raw.texel_f32 ? 4 : 2) : nullptr;
         const int mi = maskbits ? frame_mask[f] : -1;
         const bool has_masks = mi >= 0;
         const WordT *mimg = has_masks ? maskbits + (int64_t)mi * hw : nullptr;
@@ -197,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
             pu[j] = inb ? (int)u | ((int)v << 16) : 0;     // kRaw: H, W < 2^15 (checked by the entry point)
         }
         float dval[kPPT];
-        uint16_t t00[kPPT], t01[kPPT], t10[kPPT], t11[kPPT];
+        float t00[kPPT], t01[kPPT], t10[kPPT], t11[kPPT];
         float ta[kPPT], tb[kPPT];
         uint32_t sbits[kPPT], fbits[kPPT];                 // fbits (kLabels): segments in word form
 #pragma unroll
@@ -206,22 +240,19 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
             sbits[j] = 0xffffffffu;
             fbits[j] = 0xffffffffu;
             if (kRaw) {
-                t00[j] = t01[j] = t10[j] = t11[j] = 0;
+                t00[j] = t01[j] = t10[j] = t11[j] = 0.0f;
                 ta[j] = tb[j] = 0.0f;
             }
             if (pix[j] >= 0) {
                 if (kRaw) {
                     // the four source texels of the pixel (two of them when the sizes agree): all in flight together
                     const int ux = pu[j] & 0xffff, vy = pu[j] >> 16;
-                    if (raw.same) {
-                        t00[j] = rimg[raw_texel(raw, vy, ux)];
-                    } else {
-                        int x0, x1, y0, y1;
-                        axis_tap<true>(ux, raw.sx, raw.ws, x0, x1, ta[j]);
-                        axis_tap<false>(vy, raw.sy, raw.hs, y0, y1, tb[j]);
-                        t00[j] = rimg[raw_texel(raw, y0, x0)]; t01[j] = rimg[raw_texel(raw, y0, x1)];
-                        t10[j] = rimg[raw_texel(raw, y1, x0)]; t11[j] = rimg[raw_texel(raw, y1, x1)];
-                    }
+                    const uint32_t *tx = s_taps + 3 * ux, *ty = s_taps + 3 * (W + vy);
+                    const uint32_t c0 = tx[0], c1 = tx[1], r0 = ty[0], r1 = ty[1];
+                    ta[j] = __uint_as_float(tx[2]);
+                    tb[j] = __uint_as_float(ty[2]);
+                    t00[j] = sensor_texel(rimg, r0 + c0, raw); t01[j] = sensor_texel(rimg, r0 + c1, raw);
+                    t10[j] = sensor_texel(rimg, r1 + c0, raw); t11[j] = sensor_texel(rimg, r1 + c1, raw);
                 } else {
                     dval[j] = dimg[pix[j]];
                 }
@@ -241,8 +272,7 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
 #pragma unroll
             for (int j = 0; j < kPPT; ++j)
                 if (pix[j] >= 0)
-                    dval[j] = raw.same ? __fdiv_rn((float)t00[j], raw.scale)
-                                       : bilinear_depth(t00[j], t01[j], t10[j], t11[j], ta[j], tb[j], raw.scale);
+                    dval[j] = bilinear_depth(t00[j], t01[j], t10[j], t11[j], ta[j], tb[j]);
         }
         bool vis[kPPT];
         WordT wv[kPPT];
@@ -366,24 +396,16 @@ __global__ void sweep_lines_kernel(const double *__restrict__ xyz, int64_t n_poi
     if (!((u >= 0.0) && (u < (double)W) && (v >= 0.0) && (v < (double)H))) return;
     const int pix = (int)v * W + (int)u;
     float d;
-    if (is_raw) {                                                       // uint16 source texels: 64 per 128-B line
-        const uint16_t *img = reinterpret_cast<const uint16_t *>(depth) + (int64_t)depth_index[f] * raw.frame_stride;
-        auto mark = [&](int y, int x) {
-            const int64_t t = raw_texel(raw, y, x);
-            const int l = (int)(t >> 6);
+    if (is_raw) {                                                       // source texels: 64 (uint16) or 32 (float32) per 128-B line
+        const char *img = reinterpret_cast<const char *>(depth) + (int64_t)depth_index[f] * raw.frame_stride * (raw.texel_f32 ? 4 : 2);
+        auto mark = [&](uint32_t t) {
+            const int l = (int)(t >> (raw.texel_f32 ? 5 : 6));
             atomicOr(depth_lines + (int64_t)f * line_words + (l >> 5), 1u << (l & 31));
-            return img[t];
+            return sensor_texel(img, t, raw);
         };
-        if (raw.same) {
-            d = __fdiv_rn((float)mark((int)v, (int)u), raw.scale);
-        } else {
-            int x0, x1, y0, y1;
-            float a, b;
-            axis_tap<true>((int)u, raw.sx, raw.ws, x0, x1, a);
-            axis_tap<false>((int)v, raw.sy, raw.hs, y0, y1, b);
-            const uint16_t t00 = mark(y0, x0), t01 = mark(y0, x1), t10 = mark(y1, x0), t11 = mark(y1, x1);
-            d = bilinear_depth(t00, t01, t10, t11, a, b, raw.scale);
-        }
+        const uint32_t *tx = raw.taps + 3 * (int)u, *ty = raw.taps + 3 * (W + (int)v);
+        const float s00 = mark(ty[0] + tx[0]), s01 = mark(ty[0] + tx[1]), s10 = mark(ty[1] + tx[0]), s11 = mark(ty[1] + tx[1]);
+        d = bilinear_depth(s00, s01, s10, s11, __uint_as_float(tx[2]), __uint_as_float(ty[2]));
     } else {
         const int dl = pix >> 5;                                        // 32 floats per 128-B line
         atomicOr(depth_lines + (int64_t)f * line_words + (dl >> 5), 1u << (dl & 31));
@@ -737,10 +759,12 @@ static int rle_decode(const int32_t *run_start, const int32_t *run_end, const in
 }
 
 namespace bff {
-// uint16 frames [n][hs][ws] -> 8 x 8-texel tiles of 128 bytes, [n][ceil(hs/8)][ceil(ws/8)][8][8] (padding texels 0): the
-// 64 points of a wave project onto a compact patch of a frame, and the four taps of a point are neighbours in BOTH
-// directions -- in tiles they touch a fraction of the 128-byte lines that row-major frames make them touch.
-__global__ void depth_tile_kernel(const uint16_t *__restrict__ src, int hs, int ws, int th, int tw, uint16_t *__restrict__ dst)
+// uint16 frames [n][hs][ws] -> 8 x 8-texel tiles, [n][ceil(hs/8)][ceil(ws/8)][8][8] (padding texels 0): the 64 points of a
+// wave project onto a compact patch of a frame, and the four taps of a point are neighbours in BOTH directions -- in
+// tiles they touch a fraction of the 128-byte lines that row-major frames make them touch.  out_f32: the tiles hold
+// float32 metres, `astype(float32) / 1000` of P:432-435 done here once per texel instead of four times per (point, frame).
+template <typename OutT>
+__global__ void depth_tile_kernel(const uint16_t *__restrict__ src, int hs, int ws, int th, int tw, OutT *__restrict__ dst, float scale)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // one destination texel
     const int64_t per_frame = (int64_t)th * tw * 64;
@@ -748,7 +772,9 @@ __global__ void depth_tile_kernel(const uint16_t *__restrict__ src, int hs, int 
     const int f = blockIdx.y;
     const int tile = (int)(t >> 6), in = (int)(t & 63);
     const int y = (tile / tw) * 8 + (in >> 3), x = (tile % tw) * 8 + (in & 7);
-    dst[(int64_t)f * per_frame + t] = (y < hs && x < ws) ? src[((int64_t)f * hs + y) * ws + x] : (uint16_t)0;
+    const uint16_t v = (y < hs && x < ws) ? src[((int64_t)f * hs + y) * ws + x] : (uint16_t)0;
+    if constexpr (sizeof(OutT) == 4) dst[(int64_t)f * per_frame + t] = __fdiv_rn((float)v, scale);
+    else dst[(int64_t)f * per_frame + t] = v;
 }
 }  // namespace bff
 
@@ -757,8 +783,8 @@ extern "C" int64_t bff_depth_tiled_texels(int32_t h_src, int32_t w_src)
     return (int64_t)((h_src + 7) / 8) * ((w_src + 7) / 8) * 64;
 }
 
-extern "C" int bff_depth_tile_u16(const uint16_t *src, int32_t n_frames, int32_t h_src, int32_t w_src, uint16_t *dst,
-                                  void *stream)
+extern "C" int bff_depth_tile_u16(const uint16_t *src, int32_t n_frames, int32_t h_src, int32_t w_src, void *dst,
+                                  int32_t out_f32, void *stream)
 {
     BFF_REQUIRE(n_frames >= 0 && h_src > 0 && w_src > 0, "bff_depth_tile_u16: bad sizes");
     if (n_frames == 0) return BFF_OK;
@@ -766,21 +792,56 @@ extern "C" int bff_depth_tile_u16(const uint16_t *src, int32_t n_frames, int32_t
     BFF_LIMIT(n_frames <= 65535, "bff_depth_tile_u16: too many frames");
     const int th = (h_src + 7) / 8, tw = (w_src + 7) / 8;
     dim3 grid((unsigned)ceil_div((int64_t)th * tw * 64, 256), (unsigned)n_frames);
-    depth_tile_kernel<<<grid, 256, 0, as_stream(stream)>>>(src, h_src, w_src, th, tw, dst);
+    if (out_f32)
+        depth_tile_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(src, h_src, w_src, th, tw, (float *)dst, 1000.0f);
+    else
+        depth_tile_kernel<uint16_t><<<grid, 256, 0, as_stream(stream)>>>(src, h_src, w_src, th, tw, (uint16_t *)dst, 1000.0f);
     return launched("bff_depth_tile_u16");
 }
 
-static RawDepth raw_depth_params(int32_t depth_h, int32_t depth_w, int32_t height, int32_t width, int32_t tiled)
+#include <map>
+#include <mutex>
+#include <tuple>
+
+// The resize's tap table for one combination of sizes and layout lives on the device for the rest of the process (a few
+// tens of KB each, a handful of combinations): built on first use, synchronously, so that every later call on any stream
+// finds it complete.
+static int sensor_taps(int hs, int ws, int H, int W, int tiled, hipStream_t st, const uint32_t **out)
 {
-    RawDepth r;
-    r.hs = depth_h; r.ws = depth_w;
-    r.tw = tiled ? (depth_w + 7) / 8 : 0;
-    r.frame_stride = tiled ? (int64_t)((depth_h + 7) / 8) * r.tw * 64 : (int64_t)depth_h * depth_w;
-    r.same = depth_h == height && depth_w == width;
-    r.scale = 1000.0f;                                                  // depth_scale, hard-coded at P:346
-    r.sx = 1.0 / ((double)width / (double)depth_w);                     // io._axis_taps: 1 / (n_dst / n_src)
-    r.sy = 1.0 / ((double)height / (double)depth_h);
-    return r;
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int, int>, uint32_t *> cache;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail((int)e, "bff_project_views_u16: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_tuple(dev, hs, ws, H, W, tiled);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        uint32_t *table = nullptr;
+        e = hipMalloc(reinterpret_cast<void **>(&table), sizeof(uint32_t) * 3 * (size_t)(W + H));
+        if (e != hipSuccess) return fail((int)e, "bff_project_views_u16: tap table: %s", hipGetErrorString(e));
+        const double sx = 1.0 / ((double)W / (double)ws), sy = 1.0 / ((double)H / (double)hs);     // io._axis_taps: 1 / (n_dst / n_src)
+        sensor_taps_kernel<<<(unsigned)ceil_div(W + H, 256), 256, 0, st>>>(hs, ws, H, W, tiled, sx, sy, table);
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { (void)hipFree(table); return fail((int)e, "bff_project_views_u16: tap table: %s", hipGetErrorString(e)); }
+        it = cache.emplace(key, table).first;
+    }
+    *out = it->second;
+    return BFF_OK;
+}
+
+// layout: 0 uint16 row-major frames as stored, 1 uint16 in 8 x 8 tiles, 2 float32 metres in 8 x 8 tiles
+static int raw_depth_params(int32_t depth_h, int32_t depth_w, int32_t height, int32_t width, int32_t layout, hipStream_t st,
+                            RawDepth *r)
+{
+    BFF_REQUIRE(layout >= 0 && layout <= 2 && depth_h > 0 && depth_w > 0, "bff_project_views_u16: bad depth layout / size");
+    const int tiled = layout != 0;
+    r->n_taps = width + height;
+    r->texel_f32 = layout == 2;
+    r->frame_stride = tiled ? bff_depth_tiled_texels(depth_h, depth_w) : (int64_t)depth_h * depth_w;
+    r->scale = 1000.0f;                                                 // depth_scale, hard-coded at P:346
+    BFF_LIMIT(r->frame_stride < (1ll << 31), "bff_project_views_u16: depth frame too large");
+    return sensor_taps(depth_h, depth_w, height, width, tiled, st, &r->taps);
 }
 
 static int project_views_launch(const double *xyz, int64_t n_points, int64_t n_pad,
@@ -800,10 +861,12 @@ static int project_views_launch(const double *xyz, int64_t n_points, int64_t n_p
     if (n_points == 0 || n_frames == 0) return BFF_OK;
     BFF_REQUIRE(xyz && inv_pose && cam_intr_host && depth && depth_index && frame_flags, "bff_project_views: null pointer");
     BFF_REQUIRE(nw == ceil_div(n_points, 64), "bff_project_views: nw must be ceil(n_points/64)");
+    size_t taps_bytes = 0;
     if (raw) {
-        BFF_REQUIRE(raw->hs > 0 && raw->ws > 0, "bff_project_views_u16: bad depth size");
-        BFF_LIMIT(height < (1 << 15) && width < (1 << 16) && (int64_t)raw->hs * raw->ws < (1ll << 31),
-                  "bff_project_views_u16: image too large");
+        BFF_LIMIT(height < (1 << 15) && width < (1 << 16), "bff_project_views_u16: image too large");
+        taps_bytes = sizeof(uint32_t) * 3 * (size_t)raw->n_taps;
+        BFF_LIMIT(taps_bytes <= 48 * 1024, "bff_project_views_u16: the resize's tap table (12 B per image row and column) "
+                  "exceeds 48 KB of LDS: resize in a separate pass (bff_depth_from_u16)");
     }
     if (maskbits) {
         BFF_REQUIRE(word_bits == 32 || word_bits == 64, "bff_project_views: word_bits must be 32 or 64");
@@ -823,7 +886,8 @@ static int project_views_launch(const double *xyz, int64_t n_points, int64_t n_p
     g_sweep_start = g_sweep_stop = nullptr;
     const RawDepth rd = raw ? *raw : RawDepth{};
 #define BFF_SWEEP(WORD, LAB, RAW)                                                                                        \
-    hipExtLaunchKernelGGL((project_views_kernel<WORD, LAB, RAW>), grid, dim3(kBlock), 0, as_stream(stream), ev0, ev1, 0,  \
+    hipExtLaunchKernelGGL((project_views_kernel<WORD, LAB, RAW>), grid, dim3(kBlock), (unsigned)taps_bytes, as_stream(stream), \
+        ev0, ev1, 0,                                                                                                     \
         xyz, n_points, n_pad, inv_pose, K, n_frames, fpb, depth, rd, depth_index, height, width, depth_thresh,           \
         (const WORD *)maskbits, labels, label_stride, segmap, seg_words, frame_mask, frame_rowbase, frame_nmask,        \
         frame_flags, rows, nw, chunk_mask, mw, masked_count, viewed_count, tile_bounds)
@@ -855,7 +919,7 @@ extern "C" int bff_project_views(const double *xyz, int64_t n_points, int64_t n_
 
 extern "C" int bff_project_views_u16(const double *xyz, int64_t n_points, int64_t n_pad,
                                      const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
-                                     const uint16_t *depth_raw, int32_t depth_h, int32_t depth_w, int32_t depth_tiled,
+                                     const void *depth_raw, int32_t depth_h, int32_t depth_w, int32_t depth_layout,
                                      const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
                                      const void *maskbits, const uint8_t *labels, const uint32_t *segmap, int32_t word_bits,
                                      const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
@@ -864,7 +928,11 @@ extern "C" int bff_project_views_u16(const double *xyz, int64_t n_points, int64_
                                      int32_t *masked_count, int32_t *viewed_count, const double *tile_bounds,
                                      void *stream)
 {
-    const RawDepth raw = raw_depth_params(depth_h, depth_w, height, width, depth_tiled);
+    RawDepth raw;
+    if (n_points == 0 || n_frames == 0) return BFF_OK;
+    BFF_REQUIRE(height > 0 && width > 0, "bff_project_views_u16: bad image size");
+    const int rc = raw_depth_params(depth_h, depth_w, height, width, depth_layout, as_stream(stream), &raw);
+    if (rc != BFF_OK) return rc;
     return project_views_launch(xyz, n_points, n_pad, inv_pose, cam_intr_host, n_frames, depth_raw, &raw, depth_index, height,
                                 width, depth_thresh, maskbits, labels, segmap, word_bits, frame_mask, frame_rowbase,
                                 frame_nmask, frame_flags, rows, n_rows, nw, chunk_mask, masked_count, viewed_count,
@@ -925,14 +993,17 @@ extern "C" int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t
 }
 
 extern "C" int bff_diag_sweep_lines_u16(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
-                                        const double *cam_intr_host, int32_t n_frames, const uint16_t *depth_raw,
-                                        int32_t depth_h, int32_t depth_w, int32_t depth_tiled,
+                                        const double *cam_intr_host, int32_t n_frames, const void *depth_raw,
+                                        int32_t depth_h, int32_t depth_w, int32_t depth_layout,
                                         const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
                                         const uint32_t *segmap, int32_t word_bits, const int32_t *frame_mask,
                                         uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words,
                                         uint32_t *label_lines, void *stream)
 {
-    const RawDepth raw = raw_depth_params(depth_h, depth_w, height, width, depth_tiled);
+    RawDepth raw;
+    BFF_REQUIRE(height > 0 && width > 0, "bff_diag_sweep_lines_u16: bad image size");
+    const int rc = raw_depth_params(depth_h, depth_w, height, width, depth_layout, as_stream(stream), &raw);
+    if (rc != BFF_OK) return rc;
     return diag_sweep_lines(xyz, n_points, n_pad, inv_pose, cam_intr_host, n_frames, depth_raw, &raw, depth_index, height, width,
                             depth_thresh, segmap, word_bits, frame_mask, depth_lines, mask_lines, line_words, label_lines, stream);
 }

@@ -225,7 +225,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
             if keep_raw_depth():                     # resident as stored: the sweep resizes per point
                 depth_dev, raw_keep = None, raw_dev
                 if tile_raw_depth():
-                    raw_keep, raw_size = _lib.tile_depth(raw_dev), (hs, ws_)
+                    raw_keep, raw_size = _lib.tile_depth(raw_dev, metres=tile_raw_depth() == "f32"), (hs, ws_)
             else:
                 taps = None
                 if (hs, ws_) != (h, w):

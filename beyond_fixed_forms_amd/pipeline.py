@@ -112,7 +112,8 @@ def scene_struct(ds, stage1=None, n_frames=None):
     if ds.depth_raw is not None:
         s.depth, s.depth_raw = None, _p(ds.depth_raw)
         hs, ws = ds.depth_size if ds.depth_size is not None else ds.depth_raw.shape[1:3]
-        s.depth_h, s.depth_w, s.depth_tiled = int(hs), int(ws), 0 if ds.depth_size is None else 1
+        s.depth_h, s.depth_w = int(hs), int(ws)
+        s.depth_tiled = 0 if ds.depth_size is None else (2 if ds.depth_raw.dtype == torch.float32 else 1)
     else:
         s.depth, s.depth_raw = _p(ds.depth), None
     for k in ("depth_index", "frame_mask", "frame_rowbase", "frame_nmask", "frame_flags", "run_start", "run_end",

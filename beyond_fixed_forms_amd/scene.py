@@ -114,9 +114,10 @@ class DeviceScene:
     unsort: Optional[torch.Tensor] = None   # i32 [N]: position of original point o in the sorted cloud (None = unsorted)
     tile_bounds: Optional[torch.Tensor] = None   # f64 [tiles][6]: boxes of the sweep's point tiles (frustum culling)
     perm: Optional[torch.Tensor] = None     # i32 [N]: original index of sorted position s (inverse of `unsort`)
-    depth_raw: Optional[torch.Tensor] = None   # int16: the uint16 millimetres of the depth PNGs, [n_depth][hs][ws] or --
-                                               # depth_size given -- [n_depth][tiled texels] in 8 x 8 tiles; the sweep
-                                               # evaluates /1000 + the bilinear resize per point (P:432-436)
+    depth_raw: Optional[torch.Tensor] = None   # depth at the sensor's resolution: int16 [n_depth][hs][ws] (the uint16
+                                               # millimetres of the PNGs) or -- depth_size given -- [n_depth][tiled texels]
+                                               # in 8 x 8 tiles, int16 or float32 metres; the sweep evaluates the bilinear
+                                               # resize (and / 1000 for int16) per point (P:432-436)
     depth_size: Optional[tuple] = None         # (hs, ws) of the tiled frames
 
     @property
@@ -125,10 +126,13 @@ class DeviceScene:
         return self.depth_raw if self.depth_raw is not None else self.depth
 
 
-def tile_raw_depth() -> bool:
-    """Resident raw depth is re-laid in 8 x 8-texel tiles (default; BFF_DEPTH_TILES=0: row-major as stored)."""
+def tile_raw_depth():
+    """Layout of resident sensor-resolution depth: "f32" (default) 8 x 8-texel tiles of float32 metres (`/ 1000` done once
+    per texel on the way in); BFF_DEPTH_TILES=u16: tiles of the uint16 millimetres; BFF_DEPTH_TILES=0: None, the frames
+    row-major as stored.  All three give bit-identical results."""
     import os
-    return os.environ.get("BFF_DEPTH_TILES") != "0"
+    v = os.environ.get("BFF_DEPTH_TILES", "f32")
+    return None if v == "0" else ("u16" if v == "u16" else "f32")
 
 
 def keep_raw_depth() -> bool:
@@ -261,7 +265,7 @@ def prepare_scene(scene, cfg, device="cuda", with_viewed=True, sort_points=True,
         if keep_raw_depth() if raw_depth_resident is None else raw_depth_resident:
             depth_dev, raw_keep = None, raw_dev
             if tile_raw_depth():
-                raw_keep, raw_size = _lib.tile_depth(raw_dev), (hs, ws)
+                raw_keep, raw_size = _lib.tile_depth(raw_dev, metres=tile_raw_depth() == "f32"), (hs, ws)
         else:
             depth_dev = _lib.depth_from_u16(raw_dev, h, w, taps)
     elif depth_list:

@@ -138,13 +138,19 @@ int bff_project_views(const double *xyz, int64_t n_points, int64_t n_pad,
  * bff_depth_from_u16 (tap coefficients as io._axis_taps: float64 source coordinate cast to float32 before its floor is
  * subtracted, border columns copied, row indices clamped) -- results are bit-identical to bff_depth_from_u16 followed by
  * bff_project_views, the (height, width) float32 images (8 x the bytes) are never built.  height < 2^15, width < 2^16.
- * depth_tiled != 0: the frames are stored in 8 x 8-texel tiles (bff_depth_tile_u16) -- same values, fewer 128-byte lines
- * per wave: a wave's points project onto a compact patch and a point's four taps are neighbours in both directions. */
+ * depth_layout: 0 uint16 frames row-major as stored; 1 uint16 in 8 x 8-texel tiles; 2 float32 METRES in 8 x 8-texel tiles
+ * (bff_depth_tile_u16: `astype(float32) / 1000` done once per texel there) -- same values, fewer 128-byte lines per wave
+ * (a wave's points project onto a compact patch and a point's four taps are neighbours in both directions) and, for
+ * layout 2, no conversion or division left in the sweep.  The tap table of the resize (12 bytes per image row and column:
+ * two texel offsets and the fraction, as io._axis_taps) is built on the device once per size combination and staged in
+ * LDS by every block of the sweep; it must fit 48 KB (height + width <= 4096). */
 int64_t bff_depth_tiled_texels(int32_t h_src, int32_t w_src);      /* texels of one tiled frame (padded to whole tiles) */
-int bff_depth_tile_u16(const uint16_t *src, int32_t n_frames, int32_t h_src, int32_t w_src, uint16_t *dst, void *stream);
+/* dst: uint16 [n][tiled texels] (out_f32 == 0) or float32 metres [n][tiled texels] (out_f32 != 0) */
+int bff_depth_tile_u16(const uint16_t *src, int32_t n_frames, int32_t h_src, int32_t w_src, void *dst, int32_t out_f32,
+                       void *stream);
 int bff_project_views_u16(const double *xyz, int64_t n_points, int64_t n_pad,
                           const double *inv_pose, const double *cam_intr_host, int32_t n_frames,
-                          const uint16_t *depth_raw, int32_t depth_h, int32_t depth_w, int32_t depth_tiled,
+                          const void *depth_raw, int32_t depth_h, int32_t depth_w, int32_t depth_layout,
                           const int32_t *depth_index, int32_t height, int32_t width, double depth_thresh,
                           const void *maskbits, const uint8_t *labels, const uint32_t *segmap, int32_t word_bits,
                           const int32_t *frame_mask, const int32_t *frame_rowbase, const int32_t *frame_nmask,
@@ -490,7 +496,7 @@ typedef struct bff_scene {
     const double *inv_pose;         /* [n_frames][16] */
     double cam_intr[9];
     const float *depth;             /* [n_depth][height * width] metres, or NULL when depth_raw is given */
-    const uint16_t *depth_raw;      /* [n_depth][depth_h][depth_w] millimetres as stored (bff_project_views_u16), or NULL */
+    const void *depth_raw;          /* sensor-resolution frames in layout `depth_tiled` (bff_project_views_u16), or NULL */
     const int32_t *depth_index, *frame_mask, *frame_rowbase, *frame_nmask, *frame_flags;   /* [n_frames] */
     const int32_t *run_start, *run_end, *mask_run_offs, *view_mask_offs;                     /* 2-D RLE run tables */
     const void *conf;               /* [n_rows] float16 / float32 */
@@ -499,7 +505,7 @@ typedef struct bff_scene {
     const int32_t *perm;            /* [n_points] original index of sorted position s (inverse of unsort), or NULL */
     const int32_t *s1_run_start, *s1_run_end, *s1_row_run_offs;     /* stage-1 run tables or NULL */
     int32_t height, width, n_frames, n_mviews, word_bits, n_rows, conf_f16, n_label_ids, s1_rows, depth_h, depth_w,
-            depth_tiled;            /* depth_raw is in 8 x 8 tiles (bff_depth_tile_u16) */
+            depth_tiled;            /* depth_layout of bff_project_views_u16: 0 uint16 rows, 1 uint16 tiles, 2 float32 tiles */
 } bff_scene;
 
 typedef struct bff_scene_params {
@@ -585,8 +591,8 @@ int bff_diag_sweep_lines(const double *xyz, int64_t n_points, int64_t n_pad, con
 /* The same for bff_project_views_u16: depth_lines counts the 128-byte lines of the uint16 source frames (64 texels
  * per line; line_words >= ceil(ceil(depth_h * depth_w / 64) / 32) as well). */
 int bff_diag_sweep_lines_u16(const double *xyz, int64_t n_points, int64_t n_pad, const double *inv_pose,
-                             const double *cam_intr_host, int32_t n_frames, const uint16_t *depth_raw, int32_t depth_h,
-                             int32_t depth_w, int32_t depth_tiled, const int32_t *depth_index, int32_t height, int32_t width,
+                             const double *cam_intr_host, int32_t n_frames, const void *depth_raw, int32_t depth_h,
+                             int32_t depth_w, int32_t depth_layout, const int32_t *depth_index, int32_t height, int32_t width,
                              double depth_thresh, const uint32_t *segmap, int32_t word_bits, const int32_t *frame_mask,
                              uint32_t *depth_lines, uint32_t *mask_lines, int64_t line_words, uint32_t *label_lines,
                              void *stream);

@@ -24,8 +24,10 @@ cfg = Config.with_defaults(width_2d=scene.width, height_2d=scene.height)
 ds_f32 = prepare_scene(scene, cfg, device=dev)
 os.environ["BFF_DEPTH_TILES"] = "0"
 ds_u16 = prepare_scene(with_sensor_depth(scene), cfg, device=dev)
-os.environ["BFF_DEPTH_TILES"] = "1"
+os.environ["BFF_DEPTH_TILES"] = "u16"
 ds_u16t = prepare_scene(with_sensor_depth(scene), cfg, device=dev)
+os.environ["BFF_DEPTH_TILES"] = "f32"
+ds_f32t = prepare_scene(with_sensor_depth(scene), cfg, device=dev)
 n, nw, hw = ds_f32.n_points, ds_f32.nw, ds_f32.height * ds_f32.width
 n_mviews = ds_f32.view_mask_offs.shape[0] - 1
 wdt = torch.int32 if ds_f32.word_bits == 32 else torch.int64
@@ -82,6 +84,7 @@ def variants(ds, tag):
 variants(ds_f32, "f32")
 variants(ds_u16, "u16")
 variants(ds_u16t, "u16 tiles")
+variants(ds_f32t, "f32 tiles")
 viewed.zero_()
 _lib.project_views(ds_f32.xyz, n, ds_f32.inv_pose, ds_f32.cam_intr, ds_f32.depth, ds_f32.depth_index, ds_f32.height, ds_f32.width,
                    DEPTH_THRESH, None, ds_f32.word_bits, ds_f32.frame_mask, ds_f32.frame_rowbase, ds_f32.frame_nmask,

@@ -665,15 +665,19 @@ def test_sweep_resizes_raw_depth_per_point(api, case):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         exp, dbg = pref.project_scene_ref(host, cfg, return_debug=True)
-    ds_raw = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=True)            # 8 x 8-texel tiles (default)
-    os.environ["BFF_DEPTH_TILES"] = "0"
+    ds_raw = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=True)            # 8 x 8-texel tiles of float32 metres (default)
     try:
-        ds_lin = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=True)        # row-major frames, as stored
+        os.environ["BFF_DEPTH_TILES"] = "0"
+        ds_lin = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=True)        # uint16 frames row-major, as stored
+        os.environ["BFF_DEPTH_TILES"] = "u16"
+        ds_u16 = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=True)        # uint16 in tiles
     finally:
         del os.environ["BFF_DEPTH_TILES"]
     ds_two = prepare_scene(raw, cfg, device=DEV, raw_depth_resident=False)
-    assert ds_raw.depth is None and ds_raw.depth_size is not None and ds_lin.depth_size is None and ds_two.depth_raw is None
+    assert ds_raw.depth is None and ds_raw.depth_size is not None and ds_raw.depth_raw.dtype == torch.float32
+    assert ds_lin.depth_size is None and ds_u16.depth_raw.dtype == torch.int16 and ds_u16.depth_size is not None and ds_two.depth_raw is None
     c = projection.run_projection(ds_lin, cfg, debug_out=True)
+    c2 = projection.run_projection(ds_u16, cfg, debug_out=True)
     from beyond_fixed_forms_amd.scene import viewed_frame_ids
     slots = list(dict.fromkeys([fr["frame_id"][:-4] for fr in raw.mask_2d] + viewed_frame_ids(raw.color_files, cfg.downsample_ratio)))
     host_depth = torch.from_numpy(np.stack([host.depths[f].reshape(-1) for f in slots]))
@@ -681,7 +685,7 @@ def test_sweep_resizes_raw_depth_per_point(api, case):
     a = projection.run_projection(ds_raw, cfg, debug_out=True)
     b = projection.run_projection(ds_two, cfg, debug_out=True)
     for k in ("raw_rows", "masked_counts_raw", "viewed_counts"):
-        assert torch.equal(a.debug[k], b.debug[k]) and torch.equal(c.debug[k], b.debug[k]), k
+        assert torch.equal(a.debug[k], b.debug[k]) and torch.equal(c.debug[k], b.debug[k]) and torch.equal(c2.debug[k], b.debug[k]), k
     n = scene.points.shape[0]
     rawbits = np.unpackbits(a.debug["raw_rows"].cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[:, :n].astype(bool)
     assert np.array_equal(rawbits, dbg["raw_ins"].numpy())
