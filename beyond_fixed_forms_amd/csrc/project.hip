@@ -124,7 +124,25 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
     extern __shared__ uint32_t s_taps[];                   // kRaw: the resize's tap table (RawDepth::taps), 12 bytes per
                                                            // destination column / row: two LDS reads replace ~25 instructions
     if (kRaw) {
-        for (int i = threadIdx.x; i < 3 * raw.n_taps; i += kBlock) s_taps[i] = raw.taps[i];
+        // 16 bytes per load, all of a thread's loads in flight before the first store: the fill costs a block one memory
+        // latency (word by word it was ~27 dependent round trips: +330 us on config 4's 73 k blocks)
+        const int n_vec = (3 * raw.n_taps + 3) / 4;           // the table is padded to whole uint4
+        const uint4 *src = reinterpret_cast<const uint4 *>(raw.taps);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_taps);
+        constexpr int kFill = 1;                               // 8 x 256 x 16 B = 32 KB per round
+        for (int base = 0; base < n_vec; base += kFill * kBlock) {
+            uint4 v[kFill];
+#pragma unroll
+            for (int q = 0; q < kFill; ++q) {
+                const int i = base + q * kBlock + (int)threadIdx.x;
+                if (i < n_vec) v[q] = src[i];
+            }
+#pragma unroll
+            for (int q = 0; q < kFill; ++q) {
+                const int i = base + q * kBlock + (int)threadIdx.x;
+                if (i < n_vec) dst[i] = v[q];
+            }
+        }
         __syncthreads();
     }
 
@@ -818,7 +836,7 @@ static int sensor_taps(int hs, int ws, int H, int W, int tiled, hipStream_t st, 
     auto it = cache.find(key);
     if (it == cache.end()) {
         uint32_t *table = nullptr;
-        e = hipMalloc(reinterpret_cast<void **>(&table), sizeof(uint32_t) * 3 * (size_t)(W + H));
+        e = hipMalloc(reinterpret_cast<void **>(&table), sizeof(uint32_t) * (3 * (size_t)(W + H) + 4));     // read as whole uint4
         if (e != hipSuccess) return fail((int)e, "bff_project_views_u16: tap table: %s", hipGetErrorString(e));
         const double sx = 1.0 / ((double)W / (double)ws), sy = 1.0 / ((double)H / (double)hs);     // io._axis_taps: 1 / (n_dst / n_src)
         sensor_taps_kernel<<<(unsigned)ceil_div(W + H, 256), 256, 0, st>>>(hs, ws, H, W, tiled, sx, sy, table);
@@ -864,7 +882,7 @@ static int project_views_launch(const double *xyz, int64_t n_points, int64_t n_p
     size_t taps_bytes = 0;
     if (raw) {
         BFF_LIMIT(height < (1 << 15) && width < (1 << 16), "bff_project_views_u16: image too large");
-        taps_bytes = sizeof(uint32_t) * 3 * (size_t)raw->n_taps;
+        taps_bytes = sizeof(uint32_t) * ((3 * (size_t)raw->n_taps + 3) / 4 * 4);
         BFF_LIMIT(taps_bytes <= 48 * 1024, "bff_project_views_u16: the resize's tap table (12 B per image row and column) "
                   "exceeds 48 KB of LDS: resize in a separate pass (bff_depth_from_u16)");
     }

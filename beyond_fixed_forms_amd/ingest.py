@@ -222,7 +222,7 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
             from .io import bilinear_taps
             hs, ws_ = f0.shape
             raw_dev = flat.view(torch.int16).view(len(frames), hs, ws_).to(dev, non_blocking=True)
-            if keep_raw_depth():                     # resident as stored: the sweep resizes per point
+            if keep_raw_depth(n, h, w):              # resident at the sensor's resolution: the sweep resizes per point
                 depth_dev, raw_keep = None, raw_dev
                 if tile_raw_depth():
                     raw_keep, raw_size = _lib.tile_depth(raw_dev, metres=tile_raw_depth() == "f32"), (hs, ws_)

@@ -82,8 +82,6 @@ def variants(ds, tag):
 
 
 variants(ds_f32, "f32")
-variants(ds_u16, "u16")
-variants(ds_u16t, "u16 tiles")
 variants(ds_f32t, "f32 tiles")
 viewed.zero_()
 _lib.project_views(ds_f32.xyz, n, ds_f32.inv_pose, ds_f32.cam_intr, ds_f32.depth, ds_f32.depth_index, ds_f32.height, ds_f32.width,
