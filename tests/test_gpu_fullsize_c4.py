@@ -146,3 +146,72 @@ def test_c4_oracle_on_a_frame_subset_at_full_size(c4):
     got = res.to_dict()
     assert tuple(got["ins"].shape) == tuple(exp["ins"].shape) and torch.equal(got["ins"].cpu(), exp["ins"])
     assert torch.equal(got["conf"].cpu(), exp["conf"])
+
+
+def test_c4_oracle_on_twelve_frames_at_full_size(c4):
+    """Oracle (CPU) on 12 of the 600 frames at full N / HxW / M = 64 (Ins = 768): raw instance rows, both vote counters,
+    merge groups and the stage-2 result are bit-identical on the step-by-step path AND on the one-call production path
+    (native ingestion, bff_scene_project)."""
+    from beyond_fixed_forms_amd.ingest import prepare_scene_fast
+    from beyond_fixed_forms_amd.projection import projection_back, projection_front, run_projection
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    scene, cfg, _ = c4
+    sub = copy.copy(scene)
+    sub.mask_2d = [dict(f) for f in scene.mask_2d[300:312]]
+    keep = {int(f["frame_id"][:-4]) for f in sub.mask_2d}
+    sub.color_files = [f"{i}.jpg" for i in sorted(keep)]
+    cfg1 = type(cfg)(cfg); cfg1["downsample_ratio"] = 1
+    torch.set_num_threads(16)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp, dbg = pref.project_scene_ref(sub, cfg1, return_debug=True)
+    assert dbg["raw_ins"].shape[0] == 768
+    res = run_projection(prepare_scene(sub, cfg1, device=DEV), cfg1, debug_out=True)
+    n = scene.points.shape[0]
+    assert np.array_equal(bits(res.debug["raw_rows"], n), dbg["raw_ins"].numpy())
+    assert np.array_equal(res.debug["masked_counts_raw"].cpu().numpy(), dbg["masked_counts_raw"].numpy().astype(np.int32))
+    assert np.array_equal(res.debug["viewed_counts"].cpu().numpy(), dbg["viewed_counts"].numpy().astype(np.int32))
+    assert list(res.groups) == dbg["groups"] and len(dbg["groups"]) > 0
+    got = res.to_dict()
+    assert tuple(got["ins"].shape) == tuple(exp["ins"].shape) and torch.equal(got["ins"].cpu(), exp["ins"])
+    assert torch.equal(got["conf"].cpu(), exp["conf"]) and got["final_class"] == exp["final_class"]
+    del res, got
+    prod = projection_back(projection_front(prepare_scene_fast(sub, cfg1, DEV), cfg1))
+    assert prod.debug["path"] == "fast" and list(prod.groups) == dbg["groups"]
+    got = prod.to_dict()
+    assert torch.equal(got["ins"].cpu(), exp["ins"]) and torch.equal(got["conf"].cpu(), exp["conf"])
+
+
+def test_c4_size_scene_with_hundreds_of_groups(monkeypatch):
+    """A config-4-size scene (10^6 points, 968 x 1296, 64 masks per view, 24 views: Ins = 1536) whose merge graph keeps
+    several hundred groups (50 label strings): more than the default device tables hold.  (a) As shipped the scene is
+    issued again with the large tables and stays on the one-call path; (b) with the tables pinned to the default size
+    (BFF_GROUP_CAP_FIXED=1) the host continues from the components -- the general path at config-4 sizes.  Both, and the
+    step-by-step path, equal the oracle: groups, masks, confidences, labels."""
+    from beyond_fixed_forms_amd import _lib
+    from beyond_fixed_forms_amd.config import Config
+    from beyond_fixed_forms_amd.projection import run_projection
+    from beyond_fixed_forms_amd.scene import prepare_scene
+    from beyond_fixed_forms_amd.synthetic import make_scene
+    _lib.load()
+    scene = make_scene("c4", seed=3, device=DEV, n_views=24, n_labels=50, cut_masks=False)
+    cfg = Config.with_defaults(width_2d=scene.width, height_2d=scene.height)
+    torch.set_num_threads(16)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp, dbg = pref.project_scene_ref(scene, cfg, return_debug=True)
+    n_groups = len(dbg["groups"])
+    assert 256 < n_groups <= 512, n_groups
+    ds = prepare_scene(scene, cfg, device=DEV)
+    monkeypatch.setenv("BFF_GROUP_CAP_FIXED", "1")
+    general = run_projection(ds, cfg)
+    assert general.debug["path"].startswith("general") and "_group_cap" not in ds.__dict__
+    monkeypatch.delenv("BFF_GROUP_CAP_FIXED")
+    fast = run_projection(ds, cfg)
+    assert fast.debug["path"] == "fast" and ds.__dict__["_group_cap"] == 512
+    step = run_projection(ds, cfg, debug_out=True)
+    for res in (general, fast, step):
+        assert list(res.groups) == dbg["groups"]
+        got = res.to_dict()
+        assert tuple(got["ins"].shape) == tuple(exp["ins"].shape) and torch.equal(got["ins"].cpu(), exp["ins"])
+        assert torch.equal(got["conf"].cpu(), exp["conf"]) and got["final_class"] == exp["final_class"]
