@@ -2161,11 +2161,35 @@ extern "C" int64_t bff_merge_scratch_words(int32_t n_rows)
            (int64_t)kMaxSlots * (kT * kT + 1);
 }
 
+namespace bff {
+// bff_merge_components with the tile pass on a stream of its own (`heavy`; bff_scene_project keeps the chip-filling
+// kernels of the scenes in flight on shared heavy streams so that they do not run four at a time): the pre-pass and the
+// two tile-pair filters run on `stream`, `before_heavy` is recorded there and awaited by `heavy`, the tile pass runs on
+// `heavy`, `after_heavy` is recorded there and awaited by `stream`.  heavy == stream (events unused): one stream.
+int merge_components_streams(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
+                             int32_t n_order, const uint64_t *chunk_mask, uint64_t *tile_mask,
+                             const uint32_t *hist, uint32_t *scratch, const int32_t *area,
+                             const int32_t *label_id, float iou_thres, int32_t *parent, int32_t init_parent,
+                             int32_t *comp, int32_t *diag, const uint16_t *chunk_pop, void *stream, void *heavy_stream,
+                             void *before_heavy, void *after_heavy);
+}
+
 extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
                                     int32_t n_order, const uint64_t *chunk_mask, uint64_t *tile_mask,
                                     const uint32_t *hist, uint32_t *scratch, const int32_t *area,
                                     const int32_t *label_id, float iou_thres, int32_t *parent, int32_t init_parent,
                                     int32_t *comp, int32_t *diag, const uint16_t *chunk_pop, void *stream)
+{
+    return merge_components_streams(rows, n_rows, nw, order, n_order, chunk_mask, tile_mask, hist, scratch, area, label_id,
+                                    iou_thres, parent, init_parent, comp, diag, chunk_pop, stream, stream, nullptr, nullptr);
+}
+
+int bff::merge_components_streams(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
+                                  int32_t n_order, const uint64_t *chunk_mask, uint64_t *tile_mask,
+                                  const uint32_t *hist, uint32_t *scratch, const int32_t *area,
+                                  const int32_t *label_id, float iou_thres, int32_t *parent, int32_t init_parent,
+                                  int32_t *comp, int32_t *diag, const uint16_t *chunk_pop, void *stream, void *heavy_stream,
+                                  void *before_heavy, void *after_heavy)
 {
     BFF_REQUIRE(n_rows >= 0 && nw >= 0 && n_order >= 0 && n_order <= n_rows, "bff_merge_components: bad sizes");
     if (n_rows == 0) return BFF_OK;
@@ -2233,6 +2257,15 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
                                                                            mw, do_split ? part2 : nullptr, counts + 2, (int)cap2);
         const hipEvent_t ev0 = g_merge_start, ev1 = g_merge_stop;      // attached to the dispatch itself when set
         g_merge_start = g_merge_stop = nullptr;
+        const bool two = heavy_stream && heavy_stream != stream;
+        hipStream_t light = st;
+        if (two) {                                                     // the tile pass goes to the heavy stream
+            BFF_REQUIRE(before_heavy && after_heavy, "bff_merge_components: two streams need their two events");
+            hipError_t ee = hipEventRecord(reinterpret_cast<hipEvent_t>(before_heavy), light);
+            if (ee == hipSuccess) ee = hipStreamWaitEvent(as_stream(heavy_stream), reinterpret_cast<hipEvent_t>(before_heavy), 0);
+            if (ee != hipSuccess) return fail((int)ee, "bff_merge_components: stream hand-over: %s", hipGetErrorString(ee));
+            st = as_stream(heavy_stream);
+        }
         static const int diag_mode = [] { const char *e = getenv("BFF_MERGE_DIAG"); return e ? atoi(e) : 1; }();
         if (diag && diag_mode == 2)   // block timeline only (BFF_MERGE_DIAG=2): production occupancy
             hipExtLaunchKernelGGL(merge_components_kernel<2>, dim3((unsigned)cap2), dim3(256), 0, st, ev0, ev1, 0,
@@ -2246,6 +2279,12 @@ extern "C" int bff_merge_components(const uint64_t *rows, int32_t n_rows, int64_
             hipExtLaunchKernelGGL(merge_components_kernel<0>, dim3((unsigned)cap2), dim3(256), 0, st, ev0, ev1, 0,
                 rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
                 label_sorted, iou_thres, parent, nt, (int32_t *)nullptr, list2, pass2, counts + 1, chunk_pop, do_split ? part2 : nullptr, partial, arrive);
+        if (two) {
+            hipError_t ee = hipEventRecord(reinterpret_cast<hipEvent_t>(after_heavy), st);
+            if (ee == hipSuccess) ee = hipStreamWaitEvent(light, reinterpret_cast<hipEvent_t>(after_heavy), 0);
+            if (ee != hipSuccess) return fail((int)ee, "bff_merge_components: stream hand-over: %s", hipGetErrorString(ee));
+            st = light;
+        }
     }
     if (comp) uf_flatten_kernel<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(parent, n_rows, comp);
     return launched("bff_merge_components");

@@ -11,6 +11,15 @@
 
 using namespace bff;
 
+namespace bff {
+int merge_components_streams(const uint64_t *rows, int32_t n_rows, int64_t nw, const int32_t *order,
+                             int32_t n_order, const uint64_t *chunk_mask, uint64_t *tile_mask,
+                             const uint32_t *hist, uint32_t *scratch, const int32_t *area,
+                             const int32_t *label_id, float iou_thres, int32_t *parent, int32_t init_parent,
+                             int32_t *comp, int32_t *diag, const uint16_t *chunk_pop, void *stream, void *heavy_stream,
+                             void *before_heavy, void *after_heavy);
+}
+
 namespace {
 
 __global__ void order_keys_kernel(const int64_t *__restrict__ sig, const int32_t *__restrict__ label_id, int n,
@@ -86,9 +95,23 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
         Prezeroed() { scratch_prezeroed() = 1; }
         ~Prezeroed() { scratch_prezeroed() = 0; }
     } prezeroed_scope;
+    // The chip-filling kernels (decode, sweep, tile pass) go to the workspace's heavy stream when it has one: `hv`.
+    // Hand-overs by events: the call's stream -> heavy (after the fill) -> back (after the sweep) -> heavy (tile pass,
+    // inside merge_components_streams) -> back.
+    void *hv = (ws->heavy_stream && ws->heavy_stream != stream) ? ws->heavy_stream : stream;
+    const bool two = hv != stream;
+    auto hand_over = [&](void *event, void *from, void *to) -> int {
+        hipError_t ee = hipEventRecord(reinterpret_cast<hipEvent_t>(event), as_stream(from));
+        if (ee == hipSuccess) ee = hipStreamWaitEvent(as_stream(to), reinterpret_cast<hipEvent_t>(event), 0);
+        return ee == hipSuccess ? BFF_OK : fail((int)ee, "bff_scene_project: stream hand-over: %s", hipGetErrorString(ee));
+    };
+    if (two) {
+        BFF_REQUIRE(ws->events[0] && ws->events[1] && ws->events[2] && ws->events[3], "bff_scene_project: a heavy stream needs the workspace's four events");
+        BFF_TRY(hand_over(ws->events[0], stream, hv));
+    }
     // a1: 2-D RLE -> label plane (+ words where masks overlap, + segment bitmap)
     BFF_TRY(bff_rle_to_labels(sc->run_start, sc->run_end, sc->mask_run_offs, sc->view_mask_offs, sc->n_mviews, hw,
-                              sc->word_bits, ws->labels, ws->maskbits, ws->segmap, stream));
+                              sc->word_bits, ws->labels, ws->maskbits, ws->segmap, hv));
     // a2-a8 (+a15): the fused sweep.  ws->rows is all zero on entry (and again on exit, see below)
     const bool ratio = pr->filter_mode == 2;
     if (sc->depth_raw)          // depth as the PNGs store it: /1000 + bilinear resize per point inside the sweep
@@ -96,12 +119,13 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
                                       sc->depth_h, sc->depth_w, sc->depth_tiled, sc->depth_index, sc->height, sc->width, pr->depth_thresh,
                                       ws->maskbits, ws->labels, ws->segmap, sc->word_bits, sc->frame_mask, sc->frame_rowbase,
                                       sc->frame_nmask, sc->frame_flags, ws->rows, n_rows, nw, ws->chunk_mask, ws->masked,
-                                      ratio ? ws->viewed : nullptr, sc->tile_bounds, stream));
+                                      ratio ? ws->viewed : nullptr, sc->tile_bounds, hv));
     else
         BFF_TRY(bff_project_views(sc->xyz, n, sc->n_pad, sc->inv_pose, sc->cam_intr, sc->n_frames, sc->depth, sc->depth_index,
                                   sc->height, sc->width, pr->depth_thresh, ws->maskbits, ws->labels, ws->segmap, sc->word_bits,
                                   sc->frame_mask, sc->frame_rowbase, sc->frame_nmask, sc->frame_flags, ws->rows, n_rows, nw,
-                                  ws->chunk_mask, ws->masked, ratio ? ws->viewed : nullptr, sc->tile_bounds, stream));
+                                  ws->chunk_mask, ws->masked, ratio ? ws->viewed : nullptr, sc->tile_bounds, hv));
+    if (two) BFF_TRY(hand_over(ws->events[1], hv, stream));
     // a14 / a15: point filter, threshold stays on the device (header words 2, 3 = n_unique, thr)
     if (pr->filter_mode != 0) {
         if (pr->filter_sort) {          // the general formulation: sort all n values (more distinct ones than the set holds)
@@ -136,9 +160,9 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
         BFF_TRY(bff_argsort_i64(keys, ws->sig_sorted, ws->order, n_rows, key_bits, ws->sort_temp, &tb, stream));
     }
     // the forest is initialised by the tile pre-pass and flattened by the grouping step (comp == NULL here)
-    BFF_TRY(bff_merge_components(ws->rows, n_rows, nw, ws->order, n_rows, ws->chunk_mask, ws->tile_mask, ws->hist,
-                                 ws->merge_scratch, ws->area, sc->label_id, pr->iou_thres, ws->parent, 1, nullptr, nullptr,
-                                 cpop, stream));
+    BFF_TRY(merge_components_streams(ws->rows, n_rows, nw, ws->order, n_rows, ws->chunk_mask, ws->tile_mask, ws->hist,
+                                     ws->merge_scratch, ws->area, sc->label_id, pr->iou_thres, ws->parent, 1, nullptr, nullptr,
+                                     cpop, stream, hv, ws->events[2], ws->events[3]));
     // P:203-226 on the device: groups, OR of the members, sequential confidence means
     int32_t *info = hdr + BFF_HDR_K;
     BFF_TRY(bff_group_components(ws->comp, ws->parent, ws->area, n_rows, pr->iou_thres, pr->min_members, cap, ws->count, 1, info,

@@ -56,7 +56,8 @@ _WS_PTRS = ["maskbits", "segmap", "labels", "rows", "chunk_mask", "keep", "tile_
 class WorkspaceStruct(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in _WS_PTRS] + [("sort_temp_bytes", c_size_t), ("zero_bytes", c_size_t),
                                                       ("hdr", c_void_p), ("hdr_host", c_void_p),
-                                                      ("group_cap", c_int32), ("pad_", c_int32)]
+                                                      ("group_cap", c_int32), ("pad_", c_int32),
+                                                      ("heavy_stream", c_void_p), ("events", c_void_p * 4)]
 
 
 # Scenes in flight on the device, one HIP stream (and one SceneWorkspace) each.  A scene's device work is a chain of
@@ -65,8 +66,27 @@ class WorkspaceStruct(ctypes.Structure):
 # issues and collects every scene, and the chip are then both busy ~70 % of the time).
 PIPELINE_DEPTH = 4
 
+# The three chip-filling kernels of a scene (decode, sweep, tile pass) go to one of HEAVY_STREAMS shared streams: with four
+# scenes in flight on four streams they ran up to four at a time, each at a fraction of its speed (config 2: the sweep
+# 0.30 ms alone, 0.6-0.75 ms in the loop); now at most HEAVY_STREAMS of them share the chip while the scenes' chains of
+# small kernels overlap freely.  0: everything on the scene's own stream.
+HEAVY_STREAMS = int(os.environ.get("BFF_HEAVY_STREAMS", "2"))
+
 _TRACE_ISSUE = bool(os.environ.get("BFF_TRACE_ISSUE"))       # report scene calls that take more than 2 ms to enqueue
 _scene_streams = {}
+_heavy_streams = {}
+
+
+def heavy_stream(device, k):
+    """The k-th (mod HEAVY_STREAMS) heavy stream of a device, created once."""
+    if HEAVY_STREAMS <= 0:
+        return None
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    have = _heavy_streams.setdefault(idx, [])
+    while len(have) < HEAVY_STREAMS:
+        have.append(torch.cuda.Stream(device=dev))
+    return have[k % HEAVY_STREAMS]
 
 
 def scene_streams(device, depth=None):
@@ -173,6 +193,14 @@ class SceneWorkspace:
             st = torch.cuda.current_stream(device)
             ws = cls._per_stream[key] = cls(st.device)
             ws.stream = st                    # the stream this workspace belongs to (the key above is its raw handle)
+            ws.heavy = heavy_stream(st.device, len(cls._per_stream) - 1)      # workspaces take the heavy streams in turn
+            if ws.heavy is not None:
+                lib = _lib.load()
+                ws.struct.heavy_stream = c_void_p(ws.heavy.cuda_stream)
+                evs = [lib.bff_event_create() for _ in range(4)]
+                if not all(evs):
+                    raise _lib.BffLibraryError("bff_event_create failed")
+                ws.struct.events = (c_void_p * 4)(*evs)
         return ws
 
     def _need(self, name, numel, dtype, zero=False):

@@ -541,6 +541,11 @@ typedef struct bff_scene_workspace {
     int32_t group_cap;              /* BFF_GROUP_CAP or BFF_GROUP_CAP_MAX: kept groups formed on the device; agg, inter, both and the
                                        header are sized by it.  More groups than that: header flag, the host continues */
     int32_t pad_;
+    void *heavy_stream;             /* optional hipStream_t for the chip-filling kernels (decode, sweep, tile pass): callers that keep
+                                       several scenes in flight give the SAME stream to a few of them, so that at most as many
+                                       chip-filling kernels run side by side as there are heavy streams while the scenes' chains of
+                                       small kernels overlap freely.  NULL: everything on the call's stream */
+    void *events[4];                /* four hipEvent_t of this workspace for the hand-overs between the two streams (heavy_stream != NULL) */
 } bff_scene_workspace;
 
 /* Header layout (int32 words). */

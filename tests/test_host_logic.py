@@ -50,8 +50,8 @@ def test_size_limits_are_rejected_on_the_host():
     too_many_words = 8 * 4096 + 8
     assert lib.bff_row_stats(p, 1, too_many_words, p, p, p, 0, p, p, None, None) == -2 and b"4096 chunks" in lib.bff_last_error()
     assert lib.bff_merge_components(p, 64, too_many_words, None, 64, p, p, p, p, p, p, 0.2, p, 1, p, None, None, None) == -2
-    assert lib.bff_resolve_overlaps(p, 513, 10, p, p, None, p, p, p, None) == -2 and b"256 rows" in lib.bff_last_error()
-    assert lib.bff_resolve_overlaps_max_rows() == 256
+    assert lib.bff_resolve_overlaps(p, 513, 10, p, p, None, p, p, p, None) == -2 and b"512 rows" in lib.bff_last_error()
+    assert lib.bff_resolve_overlaps_max_rows() == 512
     assert lib.bff_rle_to_maskbits(p, p, p, p, 1, 1 << 31, 32, p, None, None) == -2
     assert lib.bff_rle_to_labels(p, p, p, p, 1, 1 << 31, 32, p, p, None, None) == -2
     assert lib.bff_rle_to_labels(p, p, p, p, 1, 100, 32, None, p, None, None) == -1
