@@ -66,11 +66,13 @@ class WorkspaceStruct(ctypes.Structure):
 # issues and collects every scene, and the chip are then both busy ~70 % of the time).
 PIPELINE_DEPTH = 4
 
-# The three chip-filling kernels of a scene (decode, sweep, tile pass) go to one of HEAVY_STREAMS shared streams: with four
-# scenes in flight on four streams they ran up to four at a time, each at a fraction of its speed (config 2: the sweep
-# 0.30 ms alone, 0.6-0.75 ms in the loop); now at most HEAVY_STREAMS of them share the chip while the scenes' chains of
-# small kernels overlap freely.  0: everything on the scene's own stream.
-HEAVY_STREAMS = int(os.environ.get("BFF_HEAVY_STREAMS", "2"))
+# BFF_HEAVY_STREAMS=k > 0: the three chip-filling kernels of a scene (decode, sweep, tile pass) go to one of k shared
+# streams, so that at most k of them run side by side while the scenes' chains of small kernels overlap freely (with four
+# scenes in flight on four streams they run up to four at a time, each at a fraction of its speed: config 2, the sweep
+# 0.30 ms alone, 0.6-0.8 ms in the loop).  Measured at config 2 (scenes/s): off 1047, k = 3: 875, 2: 822, 1: 760 -- every
+# one of those kernels leaves the chip half idle on its own (the sweep's waves sit on gathers 2/3 of their time) and the
+# others fill it: OFF by default (0: everything on the scene's own stream).
+HEAVY_STREAMS = int(os.environ.get("BFF_HEAVY_STREAMS", "0"))
 
 _TRACE_ISSUE = bool(os.environ.get("BFF_TRACE_ISSUE"))       # report scene calls that take more than 2 ms to enqueue
 _scene_streams = {}

@@ -17,7 +17,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 RAW=/tmp/bff_prof
 rm -rf $RAW $RAW.*
-B="python3 bench.py --no-cpu-baseline"
+B="python3 bench.py --no-cpu-baseline --no-host-inclusive"
 INC="--kernel-include-regex bff|gather_stride"
 run() { local tag=$1; shift; timeout -k 10 500 "$@" > $RAW.$tag.log 2>&1 || { echo "FAILED: $tag"; tail -5 $RAW.$tag.log; exit 1; }; echo "done: $tag ($SECONDS s)"; }
 summarize() { python3 scripts/prof_summarize.py $RAW "$OUT" ${1:-bff} > /dev/null && rm -rf $RAW; }
@@ -29,7 +29,7 @@ stats)
     summarize ;;
 seq)
     run seq rocprofv3 --kernel-trace --output-format csv -d $RAW/seq -- $B --steps 8 --warmup 4 --no-pipeline
-    python3 scripts/step_timeline.py $RAW/seq 4 > "$OUT/step_timeline_no_pipeline.txt"
+    python3 scripts/step_timeline.py $RAW/seq 4 18 > "$OUT/step_timeline_no_pipeline.txt"      # steps 18-21: inside the timed loop
     rm -rf $RAW ;;
 pmc2)
     run pmc_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace $INC --output-format csv -d $RAW/pmc_fetch -- $B --steps 8 --warmup 4 --no-pipeline
@@ -54,11 +54,12 @@ cal)
     cp $RAW.cal_fetch.log "$OUT/gather_calibration_stdout.txt"
     summarize gather_stride ;;
 bench)
-    for s in c2 c1 c4 c5; do timeout -k 10 300 $B --shape $s 2>/dev/null | tail -1 > "$OUT/bench_$s.json"; done
+    for s in c2 c1 c5; do timeout -k 10 300 $B --shape $s 2>/dev/null | tail -1 > "$OUT/bench_$s.json"; done
+    timeout -k 10 400 $B --shape c4 --scenes 2 --steps 40 --warmup 6 2>/dev/null | tail -1 > "$OUT/bench_c4.json"
     timeout -k 10 300 $B --no-pipeline 2>/dev/null | tail -1 > "$OUT/bench_c2_no_pipeline.json"
-    timeout -k 10 300 $B --shape c4 --no-pipeline 2>/dev/null | tail -1 > "$OUT/bench_c4_no_pipeline.json"
-    timeout -k 10 300 $B --include-upload 2>/dev/null | tail -1 > "$OUT/bench_c2_include_upload.json"
-    timeout -k 10 600 python3 bench.py 2>/dev/null | tail -1 > "$OUT/bench_c2_with_cpu_baseline.json"
+    timeout -k 10 400 $B --shape c4 --scenes 2 --steps 20 --warmup 4 --no-pipeline 2>/dev/null | tail -1 > "$OUT/bench_c4_no_pipeline.json"
+    for k in 1 2 3; do timeout -k 10 600 python3 bench.py 2>/dev/null | tail -1 > "$OUT/bench_c2_default_run$k.json"; done     # the driver's command: host_inclusive + cpu_baseline
+    timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_c2_driver_style.json"
     echo "done: bench ($SECONDS s)" ;;
 esac; done
 ls -la "$OUT"

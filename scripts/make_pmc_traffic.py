@@ -52,7 +52,8 @@ for shape, suffix in (("c2", ""), ("c4", "_c4")):
         continue
     fetch_kb, nf = f[fk[0]][0], f[fk[0]][1]
     write_kb = w[wk[0]][0]
-    out[f"project_views_{shape}"] = {
+    # config 2 keeps its depth at the sensor's resolution (bench.py looks the entry up as ..._u16), config 4 as float32 (H, W)
+    out[f"project_views_{shape}" + ("_u16" if shape == "c2" else "")] = {
         "bytes": int(round(fetch_kb * 1024 * corr + write_kb * 1024)),
         "fetch_kb_raw": round(fetch_kb), "write_kb": round(write_kb), "fetch_correction": corr, "dispatches": nf,
         "fetch_kb_min_max": [round(f[fk[0]][2]), round(f[fk[0]][3])],
