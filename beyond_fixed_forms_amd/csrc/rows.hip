@@ -109,7 +109,10 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
             // pair flags meet through atomics in the zeroed outputs, as with split tiles.
             const int64_t blocks = (int64_t)gridDim.x * gridDim.y * gridDim.z;
             const int64_t slice = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            const int64_t per = ceil_div_dev(ceil_div_dev(nw, blocks), kKW) * kKW;       // words per block, whole stages
+            // >= 4 stages per block: every block adds its partial counts with one atomic per pair, and 98 blocks x 276
+            // pairs on the same 2 KB of counters took 57 us at config 2 (K = 23) where 25 blocks take a fraction of that
+            int64_t per = ceil_div_dev(ceil_div_dev(nw, blocks), kKW) * kKW;             // words per block, whole stages
+            if (per < 4 * kKW) per = 4 * kKW;
             const int64_t k_lo = slice * per, k_hi = min(nw, k_lo + per);
             if (k_lo >= nw || kd <= 0) return;                    // block-uniform
             const int lk = threadIdx.x & (kKW - 1), lr = threadIdx.x >> 5;
@@ -1757,6 +1760,12 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
         for (int r = threadIdx.x; r < k; r += kWave) before[r] = inter[(int64_t)r * stride + r];
     constexpr int kPitch = kWave + 1;                        // column- and row-wise LDS accesses both conflict-free
     __shared__ int s_size[kFuseMax];
+    // pair masks of the rows: in LDS for the word-column form (<= 256 rows x 4 words = 8 KB; one dependent global load per
+    // row made the 20-row scenes of the benchmark 2 x slower: 118 -> 190 us), straight from global memory for the
+    // half-word form, whose 512 columns x 65 x 4 B leave no room for 32 KB of masks
+    constexpr bool kMaskLds = sizeof(ColT) == 8;
+    constexpr int kMaskW = kFuseMax / 2 / 64;                // mask words of a row that can be non-zero in the word-column form
+    __shared__ unsigned long long s_mask[kMaskLds ? (kFuseMax / 2) * kMaskW : 1];
     extern __shared__ uint64_t s_dyn[];
     ColT *s_col = reinterpret_cast<ColT *>(s_dyn);           // [k][kPitch]
     const int t = threadIdx.x;
@@ -1765,7 +1774,9 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
     const int64_t ncol = nw * (int64_t)(sizeof(uint64_t) / sizeof(ColT));      // columns of ColT per row
     const int64_t w = (int64_t)blockIdx.x * kWave + t;
     const int kw = (k + 63) / 64;
-    // independent loads, several in flight: the sizes, then this thread's column of every row
+    // independent loads, several in flight: the pair masks, the sizes, then this thread's column of every row
+    if (kMaskLds)
+        for (int q = t; q < k * kMaskW; q += kWave) s_mask[q] = pmask[(int64_t)(q / kMaskW) * kMW + (q % kMaskW)];
     for (int r = t; r < k; r += kWave) s_size[r] = size[r];
 #pragma unroll 8
     for (int r = 0; r < k; ++r) s_col[r * kPitch + t] = w < ncol ? rows[(int64_t)r * ncol + w] : 0;
@@ -1779,7 +1790,7 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
         const int size_i = s_size[i];
         bool touched = false;
         for (int q = 0; q < kw; ++q) {
-            unsigned long long m = pmask[(int64_t)i * kMW + q];       // wave-uniform
+            unsigned long long m = kMaskLds ? s_mask[i * kMaskW + q] : pmask[(int64_t)i * kMW + q];       // wave-uniform
             while (m) {
                 int js[8];
                 ColT v[8];
