@@ -504,7 +504,9 @@ def main():
     upload_leg = None
     if world == 1 and not args.no_host_inclusive:
         from beyond_fixed_forms_amd.ingest import bench_host_inclusive
-        upload_leg = bench_host_inclusive(scenes, cfg, dev, QUERY, sim, steps=min(max(args.steps, 24), 48))
+        upload_leg = bench_host_inclusive(scenes, cfg, dev, QUERY, sim, steps=min(max(args.steps, 24), 48),
+                                          n_loaders=int(os.environ.get("BFF_BENCH_LOADERS", "4")),
+                                          native_threads=int(os.environ.get("BFF_BENCH_NATIVE_THREADS", "4")))
 
     # what rank 0 holds after the last class: every rank's final masks, decoded from the gathered buffers only now
     gathered_check = None

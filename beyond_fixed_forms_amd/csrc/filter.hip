@@ -244,18 +244,28 @@ __global__ __launch_bounds__(1024) void select_rank_kernel(const uint32_t *__res
             if ((v & mask) == prefix) atomicAdd(&hist[wave][(v >> shift) & 255u], 1u);
         }
         __syncthreads();
+        // bin of the rank: inclusive prefix over the 256 bins by the first four waves (one serial walk by one thread cost
+        // ~7 us per pass: 255 dependent LDS reads), then the one bin whose prefix interval holds the rank reports itself
+        uint32_t mine = 0, incl = 0;
         if (tid < 256) {
-            uint32_t t = 0;
 #pragma unroll
-            for (int w = 0; w < 16; ++w) t += hist[w][tid];
-            total[tid] = t;
+            for (int w = 0; w < 16; ++w) mine += hist[w][tid];
+            incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if ((tid & 63) >= d) incl += up; }
+            if ((tid & 63) == 63) total[tid >> 6] = incl;              // the four waves' sums
         }
         __syncthreads();
-        if (tid == 0) {
-            uint32_t r = s_rank, b = 0;
-            while (b < 255 && r >= total[b]) { r -= total[b]; ++b; }
-            s_rank = r;
-            s_prefix = prefix | (b << shift);
+        if (tid < 256) {
+            uint32_t before = 0;
+            for (int w = 0; w < (tid >> 6); ++w) before += total[w];
+            incl += before;
+            const uint32_t r = s_rank;                                  // read by all before anyone writes (barrier below)
+            const bool here = r < incl && r >= incl - mine;
+            __syncthreads();
+            if (here) { s_rank = r - (incl - mine); s_prefix = prefix | ((uint32_t)tid << shift); }
+        } else {
+            __syncthreads();
         }
         __syncthreads();
     }

@@ -1494,14 +1494,31 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restr
         __syncthreads();
     }
     const int k_all = s_base, k = min(k_all, cap);
-    if (tid == 0) {
-        int o = 0, so = 0;
-        for (int g = 0; g < k; ++g) { s_off[g] = o; s_soff[g] = so; o += s_sz[g]; so += (s_sz[g] + kOrSplit - 1) / kOrSplit; }
-        s_off[k] = o; s_soff[k] = so;
-        info[0] = k_all;
-        info[1] = (k_all > cap ? 1 : 0) | ((min_members <= 0 && s_void > 0) ? 2 : 0);
-        info[2] = s_max;
-        info[3] = min(so, slice_cap);
+    {
+        // exclusive prefix sums of the groups' sizes and 32-member slice counts over the k <= 512 groups: thread g owns
+        // group g (one serial walk by one thread: up to 512 dependent LDS round trips, 20+ us for scenes with many groups)
+        const int sz = tid < k ? s_sz[tid] : 0, sl = (sz + kOrSplit - 1) / kOrSplit;
+        int io = sz, is = sl;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int uo = __shfl_up(io, d), us = __shfl_up(is, d);
+            if (lane >= d) { io += uo; is += us; }
+        }
+        __syncthreads();                               // wsum was last read two barriers ago; reuse it for both sums
+        __shared__ int wsum2[16];
+        if (lane == 63) { wsum[wave] = io; wsum2[wave] = is; }
+        __syncthreads();
+        int bo = 0, bs = 0;
+        for (int q = 0; q < wave; ++q) { bo += wsum[q]; bs += wsum2[q]; }
+        if (tid < k) { s_off[tid] = bo + io - sz; s_soff[tid] = bs + is - sl; }
+        if (tid == k - 1 || (k == 0 && tid == 0)) {
+            const int o = k ? bo + io : 0, so = k ? bs + is : 0;
+            s_off[k] = o; s_soff[k] = so;
+            info[0] = k_all;
+            info[1] = (k_all > cap ? 1 : 0) | ((min_members <= 0 && s_void > 0) ? 2 : 0);
+            info[2] = s_max;
+            info[3] = min(so, slice_cap);
+        }
     }
     __syncthreads();
     for (int g = tid; g <= k; g += 1024) offs[g] = s_off[g];
