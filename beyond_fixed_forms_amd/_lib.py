@@ -36,7 +36,7 @@ SIGNATURES = {
     "bff_permute_bits": [_P, _I, _L, _P, _L, _L, _P, _P],
     "bff_components_round": [_P, _I, _P, _P, _P, _P],
     "bff_or_reduce_groups": [_P, _L, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P],
-    "bff_resolve_overlaps": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P],
+    "bff_resolve_overlaps": [_P, _I, _L, _P, _P, _P, _P, _P],
     "bff_group_conf_mean": [_P, _I, _P, _P, _I, _P, _P],
     "bff_apply_row_ops": [_P, _L, _P, _I, _P],
     "bff_overlap_ops": [_P, _P, _I, _P, _P],
@@ -58,14 +58,14 @@ SIGNATURES = {
     "bff_description_means": [_P, _P, _I, _I, _I, _P, _P],
     "bff_group_components": [_P, _P, _P, _I, _F, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "bff_or_reduce_grouped": [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],
-    "bff_resolve_overlaps_dev": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P],
+    "bff_resolve_overlaps_dev": [_P, _I, _L, _P, _P, _P, _P, _P, _P],
     "bff_clear_flagged_chunks_unless": [_P, _I, _L, _P, _P, _P],
     "bff_scene_project": [_P, _P, _P, _P],
     "bff_diag_gather": [_P, _L, _L, _P, _P],
     "bff_diag_sweep_lines": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _I, _D, _P, _I, _P, _P, _P, _L, _P, _P],
     "bff_diag_sweep_lines_u16": [_P, _L, _L, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _D, _P, _I, _P, _P, _P, _L, _P, _P],
     "bff_scatter_bits": [_P, _I, _L, _P, _L, _L, _P, _P, _P],
-    "bff_cross_popcount_dev": [_P, _I, _P, _I, _L, _P, _P, _I, _I, _P, _P],
+    "bff_cross_popcount_dev": [_P, _I, _P, _I, _L, _P, _P, _I, _I, _P],
     "bff_cloud_layout": [_P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "bff_sort_f32": [_P, _P, _L, _P, _P, _P],
     "bff_argsort_i64": [_P, _P, _P, _I, _I, _P, _P, _P],
@@ -75,11 +75,11 @@ PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, [
          "bff_chunk_mask_words": (c_int32, [c_int64]), "bff_label_plane_stride": (c_int64, [c_int64]), "bff_resolve_overlaps_max_rows": (c_int32, []),
          "bff_point_tile_size": (c_int32, []), "bff_depth_tiled_texels": (c_int64, [c_int32, c_int32]), "bff_merge_scratch_words": (c_int64, [c_int32]), "bff_merge_uses_chunk_bound": (c_int32, [c_int64]),
          "bff_profile_next_merge": (c_int32, [_P, _P]), "bff_group_slice_cap": (c_int32, [c_int32, c_int32]),
-         "bff_resolve_overlaps_scratch_words": (c_int64, []), "bff_point_threshold_scratch_words": (c_int64, [c_int64]), "bff_point_threshold_capacity": (c_int32, []), "bff_point_threshold_capacity_set": (c_int32, [c_int32]), "bff_scene_header_words": (c_int32, [c_int32, c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
+         "bff_point_threshold_scratch_words": (c_int64, [c_int64]), "bff_point_threshold_capacity": (c_int32, []), "bff_point_threshold_capacity_set": (c_int32, [c_int32]), "bff_scene_header_words": (c_int32, [c_int32, c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
          "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
          "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class BffLibraryError(RuntimeError):
@@ -441,6 +441,14 @@ def apply_row_ops(rows, ops):
 def resolve_overlaps(rows, sizes):
     """solve_overlapping P:277-301 on bit rows, in place, without leaving the device.
     sizes: int32 device tensor, number of raw masks merged into each row."""
+    if rows.shape[0] >= 2:
+        resolve_overlaps_filtered(rows, sizes, None)
+
+
+def resolve_overlaps_replay(rows, sizes):
+    """The same as the reference spells it: the ordered list of overlapping pairs (intersections before any edit), then
+    one and-not per pair in that order.  Three launches; the cross-check of the closed form and the path for more rows
+    than bff_resolve_overlaps_max_rows()."""
     k = rows.shape[0]
     if k < 2:
         return
@@ -451,24 +459,20 @@ def resolve_overlaps(rows, sizes):
 
 
 def resolve_overlaps_filtered(rows, sizes, keep):
-    """solve_overlapping (P:277-301), `&= keep` (P:595) and the popcounts before / after (P:592, 596) in two
-    launches (intersections, then one fused pass) -> (before, after) int32 device tensors.  More than
-    bff_resolve_overlaps_max_rows() rows: the same through the separate entry points."""
+    """solve_overlapping (P:277-301), `&= keep` (P:595; None: no filter) and the popcounts before / after (P:592, 596) in
+    one launch -> (before, after) int32 device tensors.  More than bff_resolve_overlaps_max_rows() rows: the ordered
+    replay and the separate steps."""
     k = rows.shape[0]
-    inter = cross_popcount(rows, rows)
     if k <= load().bff_resolve_overlaps_max_rows():
         before = torch.empty(k, dtype=i32, device=rows.device)
         after = torch.empty(k, dtype=i32, device=rows.device)
-        pm = torch.empty(int(load().bff_resolve_overlaps_scratch_words()), dtype=i64, device=rows.device)
-        call("bff_resolve_overlaps", _ptr(rows, i64), k, rows.shape[1], _ptr(inter, i32), _ptr(sizes, i32),
-             _ptr(keep, i64), _ptr(before), _ptr(after), _ptr(pm))
+        call("bff_resolve_overlaps", _ptr(rows, i64), k, rows.shape[1], _ptr(sizes, i32),
+             _ptr(keep, i64) if keep is not None else None, _ptr(before), _ptr(after))
         return before, after
-    before = inter.diagonal().contiguous()
-    if k >= 2:
-        ops = torch.empty(1 + 3 * (k * (k - 1) // 2), dtype=i32, device=rows.device)
-        call("bff_overlap_ops", _ptr(inter, i32), _ptr(sizes, i32), k, _ptr(ops))
-        call("bff_apply_row_ops", _ptr(rows, i64), rows.shape[1], _ptr(ops), -1)
-    and_rows(rows, keep)
+    before = popcount_rows(rows)
+    resolve_overlaps_replay(rows, sizes)
+    if keep is not None:
+        and_rows(rows, keep)
     return before, popcount_rows(rows)
 
 

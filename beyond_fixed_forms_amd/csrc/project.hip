@@ -525,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
     const int32_t *__restrict__ run_start, const int32_t *__restrict__ run_end,
     const int32_t *__restrict__ mask_run_offs, const int32_t *__restrict__ view_mask_offs,
     int64_t n_pixels, WordT *__restrict__ maskbits, uint32_t *__restrict__ segmap, int64_t seg_words,
-    uint8_t *__restrict__ labels, int64_t label_stride)
+    uint8_t *__restrict__ labels, int64_t label_stride, int band_chunks)
 {
     __shared__ WordT lds[kBlock / kWave][kWaveChunk];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
     const int v = blockIdx.y;
     const int g0 = view_mask_offs[v];
     const int nm = view_mask_offs[v + 1] - g0;
-    const int64_t band64 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kWaveChunk * kWaveChunks;
+    const int64_t band64 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kWaveChunk * band_chunks;
     if (band64 >= n_pixels) return;                  // wave-uniform
     const int band0 = (int)band64, npx = (int)n_pixels;               // n_pixels < 2^31 (checked by the entry point)
     WordT *img = maskbits + (int64_t)v * n_pixels;
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
     lds_phase_fence();
     const WordT bit = (WordT)1 << (lane & (int)(sizeof(WordT) * 8 - 1));
     uint32_t *smap = segmap ? segmap + (int64_t)v * seg_words * (kLabels ? 2 : 1) : nullptr;
-    for (int c = 0; c < kWaveChunks; ++c) {
+    for (int c = 0; c < band_chunks; ++c) {
         const int c0 = band0 + c * kWaveChunk;        // scalar
         if (c0 >= npx) break;
         const bool whole = npx - c0 >= kWaveChunk;    // every chunk but the image's last one
@@ -752,7 +752,9 @@ static int rle_decode(const int32_t *run_start, const int32_t *run_end, const in
     BFF_LIMIT(n_pixels < (1ll << 31), "bff_rle_to_maskbits: image larger than 2^31 pixels");
     if (n_views == 0) return BFF_OK;
     BFF_REQUIRE(mask_run_offs && view_mask_offs && maskbits, "bff_rle_to_maskbits: null pointer");   // run arrays may be empty (NULL)
-    dim3 grid((unsigned)ceil_div(n_pixels, (int64_t)kWaveChunk * kWaveChunks * (kBlock / kWave)), (unsigned)n_views);
+    static const int band_env = [] { const char *e = getenv("BFF_RLE_BAND"); return e ? atoi(e) : 0; }();
+    const int band = band_env > 0 ? band_env : kWaveChunks;
+    dim3 grid((unsigned)ceil_div(n_pixels, (int64_t)kWaveChunk * band * (kBlock / kWave)), (unsigned)n_views);
     const int64_t seg_words = ceil_div(ceil_div(n_pixels, 128), 32);
     BFF_REQUIRE(!labels || segmap, "bff_rle_to_labels: the label plane needs its segment bitmap");
     if (segmap) {
@@ -763,16 +765,16 @@ static int rle_decode(const int32_t *run_start, const int32_t *run_end, const in
     hipStream_t st = as_stream(stream);
     if (word_bits == 32 && !labels)
         rle_to_maskbits_kernel<uint32_t, false><<<grid, kBlock, 0, st>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words, nullptr, 0);
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words, nullptr, 0, band);
     else if (word_bits == 32)
         rle_to_maskbits_kernel<uint32_t, true><<<grid, kBlock, 0, st>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words, labels, ls);
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words, labels, ls, band);
     else if (!labels)
         rle_to_maskbits_kernel<uint64_t, false><<<grid, kBlock, 0, st>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words, nullptr, 0);
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words, nullptr, 0, band);
     else
         rle_to_maskbits_kernel<uint64_t, true><<<grid, kBlock, 0, st>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words, labels, ls);
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words, labels, ls, band);
     return launched("bff_rle_to_maskbits");
 }
 

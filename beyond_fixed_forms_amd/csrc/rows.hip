@@ -85,16 +85,14 @@ __device__ __forceinline__ void tile_popcount(const uint64_t *__restrict__ a, co
     }
 }
 
-constexpr int kFuseMax = BFF_GROUP_CAP_MAX;      // most rows of the fused overlap pass = most groups the device forms by itself
-constexpr int kMW = kFuseMax / 64;               // words of one row's pair mask
+constexpr int kFuseMax = BFF_GROUP_CAP_MAX;      // most groups the device forms by itself
 
 __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__restrict__ a,
                                                               const int32_t *__restrict__ ia, int na,
                                                               const uint64_t *__restrict__ b,
                                                               const int32_t *__restrict__ ib, int nb, int64_t nw,
                                                               int64_t k_split, int32_t *__restrict__ inter,
-                                                              const int32_t *__restrict__ k_dev, int lim_a, int hole_hi,
-                                                              unsigned long long *__restrict__ pmask)
+                                                              const int32_t *__restrict__ k_dev, int lim_a, int hole_hi)
 {
     __shared__ uint64_t sa[kKW][kPitch], sb[kKW][kPitch];
     // k_dev (optional): only the first *k_dev rows of a (when lim_a) resp. of b's leading block [0, hole_hi) hold data,
@@ -102,43 +100,8 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
     // zeroed by the host when the words are split over z; callers never read the skipped entries otherwise)
     if (k_dev) {
         const int kd = *k_dev;
-        if (lim_a == 2 && kd <= kT) {
-            // a == b and at most 64 live rows (the usual number of kept groups is a few dozen): a 64 x 64 tile would spend
-            // its time on rows that are zero.  Every block takes one 32-word slice of the live rows instead (blocks beyond
-            // the slices leave), thread p adds up pairs p, p + 256, ... of the upper triangle, and the partial counts and
-            // pair flags meet through atomics in the zeroed outputs, as with split tiles.
-            const int64_t blocks = (int64_t)gridDim.x * gridDim.y * gridDim.z;
-            const int64_t slice = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            // >= 4 stages per block: every block adds its partial counts with one atomic per pair, and 98 blocks x 276
-            // pairs on the same 2 KB of counters took 57 us at config 2 (K = 23) where 25 blocks take a fraction of that
-            int64_t per = ceil_div_dev(ceil_div_dev(nw, blocks), kKW) * kKW;             // words per block, whole stages
-            if (per < 4 * kKW) per = 4 * kKW;
-            const int64_t k_lo = slice * per, k_hi = min(nw, k_lo + per);
-            if (k_lo >= nw || kd <= 0) return;                    // block-uniform
-            const int lk = threadIdx.x & (kKW - 1), lr = threadIdx.x >> 5;
-            const int n_pairs = kd * (kd + 1) / 2;
-            for (int64_t k0 = k_lo; k0 < k_hi; k0 += kKW) {
-                for (int r = lr; r < kd; r += 8) sa[lk][r] = k0 + lk < nw ? a[(int64_t)r * nw + k0 + lk] : 0;
-                __syncthreads();
-                for (int p = threadIdx.x; p < n_pairs; p += 256) {
-                    int i = 0, rest = p;                           // p -> (i <= j): row i owns kd - i pairs
-                    while (rest >= kd - i) { rest -= kd - i; ++i; }
-                    const int j = i + rest;
-                    int c = 0;
-#pragma unroll 8
-                    for (int kk = 0; kk < kKW; ++kk) c += popc64(sa[kk][i] & sa[kk][j]);
-                    if (c) {
-                        atomicAdd(inter + (int64_t)i * nb + j, c);
-                        if (pmask && j > i) atomicOr(pmask + (int64_t)i * kMW + (j >> 6), 1ull << (j & 63));
-                    }
-                }
-                __syncthreads();
-            }
-            return;
-        }
         if (lim_a && (int)blockIdx.y * kT >= kd) return;
         if ((int)blockIdx.x * kT >= kd && (int)(blockIdx.x + 1) * kT <= hole_hi) return;
-        if (lim_a == 2 && blockIdx.y > blockIdx.x) return;        // a == b and only entries j >= i are read
     }
     // blockIdx.z owns the word range [z*k_split, (z+1)*k_split): small row counts still fill the chip.
     // Partial counts are combined with integer atomics (exact, order independent) into a zeroed matrix.
@@ -157,26 +120,6 @@ __global__ __launch_bounds__(256) void cross_popcount_kernel(const uint64_t *__r
                 else if (acc[r][c]) atomicAdd(inter + (int64_t)i * nb + j, acc[r][c]);
             }
         }
-    if (pmask) {
-        // pair flags of solve_overlapping (P:289-292), a == b: pmask[i] bit j = rows j > i that overlap row i.  The words
-        // of a block are a partial intersection; a pair overlaps iff some part of it does, so the parts' flags are OR-ed
-        // into the zeroed mask (kMW words per row).  Thread (ti, tj) holds the flags of a 4 x 4 patch: row i's 64
-        // columns of this tile meet in LDS.
-        __shared__ uint8_t flag[kT][kT + 4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int i = i0 + ti * 4 + r, j = j0 + tj * 4 + c;
-                flag[ti * 4 + r][tj * 4 + c] = (i < na && j < nb && j > i && acc[r][c] > 0) ? 1 : 0;
-            }
-        __syncthreads();
-        if (threadIdx.x < kT && i0 + (int)threadIdx.x < na && (int)blockIdx.x < kMW && i0 + (int)threadIdx.x < kFuseMax) {
-            unsigned long long w = 0;
-            for (int c = 0; c < kT; ++c) w |= (unsigned long long)flag[threadIdx.x][c] << c;
-            if (w) atomicOr(pmask + (int64_t)(i0 + threadIdx.x) * kMW + blockIdx.x, w);
-        }
-    }
 }
 
 // ---- row statistics for the block-sparse Gram -------------------------------------------------
@@ -1721,48 +1664,83 @@ __global__ void apply_row_ops_kernel(uint64_t *__restrict__ rows, int64_t nw, co
     }
 }
 
-// solve_overlapping (P:285-299) + the point filter (P:595) + both popcounts (P:592, 596) in one pass for K <= 64
-// rows.  One wave per 64 word columns: the K words of a column live in LDS, every thread replays the reference's
-// ordered pair loop on its own column (the pair flags come from the intersections BEFORE any edit, P:289-292),
-// ANDs with `keep`, writes the column back and the wave adds the columns' popcounts to after[].
+// solve_overlapping (P:277-301) + the point filter (P:595) + both popcounts (P:592, 596) in ONE pass, for any number
+// of rows.
+//
+// The reference lists the pairs (i < j) that share a point BEFORE any edit and visits them in (i, j) order: the row
+// merged from more raw masks keeps the current overlap, the other loses it, ties go to j (P:285-299).  Seen from ONE
+// point p this is a walk over S = the rows that hold p at the start (every pair inside S shares p, so every one of
+// them is on the list; rows outside S neither change at p nor change others there).  A row's bit is only ever
+// cleared, and a pair with a cleared bit changes nothing, so the walk is a champion scan over S in index order: the
+// first row stays until it meets a row of at least its size, which then takes its place, and so on.  Champion sizes
+// never decrease and a later equal size replaces the champion, hence
+//     p ends up in exactly one row of S: the one with the largest size, and among those the LARGEST index.
+// With the rows ordered by that priority (size descending, index descending) the whole loop is one exclusive prefix
+// OR: row r keeps  r & ~(OR of the rows ranked before it).  No pair list, no intersections, no order dependence
+// between words.  (tests: against the literal ordered replay, bff_overlap_ops + bff_apply_row_ops, and the oracle.)
+//
+// One block = 64 word columns x 16 waves; wave s owns the ranks [s L, (s+1) L), L = ceil(k / 16): it loads its rows'
+// words (independent loads, all in flight), ORs them, the 16 segment sums meet in LDS, and every row is finished with
+// the OR of the segments before its own plus its own exclusive prefix.  Rows that do not change are not written.
+constexpr int kResWaves = 16;
+constexpr int kResolveMax = 4096;          // rows: the ranks are found by counting, k^2 / 1024 comparisons per thread
 
-// Pair flags of solve_overlapping (P:289-292) from the intersections BEFORE any edit: pmask[i] = bit set over the
-// rows j > i that overlap row i (kFuseMax / 64 words per row), before[i] = |row i| (P:592).  One wave per row.
-__global__ __launch_bounds__(256) void overlap_masks_kernel(const int32_t *__restrict__ inter, int stride, int k,
-                                                             const int32_t *__restrict__ k_dev,
-                                                             unsigned long long *__restrict__ pmask,
-                                                             int32_t *__restrict__ before)
+__device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
 {
-    if (k_dev) {
-        const int kd = *k_dev;
-        if (kd <= 0 || kd > k) return;
-        k = kd;
-    }
-    const int lane = lane_id();
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= k) return;
-#pragma unroll
-    for (int q = 0; q < kMW; ++q) {
-        const int j = 64 * q + lane;
-        const int v = j < k ? inter[(int64_t)i * stride + j] : 0;
-        const unsigned long long m = __ballot(v > 0 && j > i);
-        if (lane == 0) pmask[(int64_t)i * kMW + q] = m;
-        if (j == i) before[i] = v;
+#define BFF_DPP_ADD(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xF, false)
+    BFF_DPP_ADD(0x111, 0xF);    // row_shr:1
+    BFF_DPP_ADD(0x112, 0xF);    // row_shr:2
+    BFF_DPP_ADD(0x114, 0xF);    // row_shr:4
+    BFF_DPP_ADD(0x118, 0xF);    // row_shr:8
+    BFF_DPP_ADD(0x142, 0xA);    // row_bcast:15 -> rows 1 and 3
+    BFF_DPP_ADD(0x143, 0xC);    // row_bcast:31 -> rows 2 and 3
+#undef BFF_DPP_ADD
+    return v;                   // lane 63 holds the sum of all 64 lanes
+}
+
+// one finished row: write it if it changed, add its popcounts before / after (<= 4096 each per wave: two 16-bit fields)
+__device__ __forceinline__ void resolve_emit(uint64_t *__restrict__ dst, uint64_t v, uint64_t out, bool in, int row,
+                                             int32_t *__restrict__ before, int32_t *__restrict__ after, int lane)
+{
+    if (in && out != v) *dst = out;
+    const uint32_t pc = wave_sum_to_lane63(((uint32_t)popc64(v) << 16) | (uint32_t)popc64(out));
+    if (lane == kWave - 1) {
+        if (pc >> 16) atomicAdd(before + row, (int)(pc >> 16));
+        if (pc & 0xffffu) atomicAdd(after + row, (int)(pc & 0xffffu));
     }
 }
 
-// ColT = uint64_t: a block works on 64 word columns (k <= 256 rows: 133 KB of LDS); uint32_t: on 64 HALF-word columns
-// (32 words), which lets twice as many rows fit (k <= 512) -- the pass is bitwise, so halves of words are columns like
-// any other.  The pair masks are wave-uniform and come straight from global memory (scalar loads).
-template <typename ColT>
-__global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restrict__ rows64, int64_t nw, int k,
-                                                              const unsigned long long *__restrict__ pmask,
-                                                              const int32_t *__restrict__ size,
-                                                              const uint64_t *__restrict__ keep64,
-                                                              int32_t *__restrict__ after,
-                                                              const int32_t *__restrict__ k_dev,
-                                                              const int32_t *__restrict__ inter, int stride,
-                                                              int32_t *__restrict__ before)
+template <int kMaxL>
+__device__ __forceinline__ void resolve_segment_in_registers(uint64_t *__restrict__ rows, int64_t nw, int64_t w, bool in,
+                                                             int r0, int r1, const int *s_order, uint64_t (*s_seg)[kWave],
+                                                             uint64_t kp, int32_t *__restrict__ before,
+                                                             int32_t *__restrict__ after, int lane, int wave)
+{
+    uint64_t v[kMaxL];
+#pragma unroll
+    for (int q = 0; q < kMaxL; ++q)                                  // r0 + q < r1 is wave-uniform
+        v[q] = (r0 + q < r1 && in) ? rows[(int64_t)s_order[r0 + q] * nw + w] : 0;
+    uint64_t tot = 0;
+#pragma unroll
+    for (int q = 0; q < kMaxL; ++q) tot |= v[q];
+    s_seg[wave][lane] = tot;
+    __syncthreads();
+    uint64_t claimed = 0;
+    for (int s = 0; s < wave; ++s) claimed |= s_seg[s][lane];
+#pragma unroll
+    for (int q = 0; q < kMaxL; ++q)
+        if (r0 + q < r1) {
+            const int row = s_order[r0 + q];
+            resolve_emit(rows + (int64_t)row * nw + w, v[q], v[q] & ~claimed & kp, in, row, before, after, lane);
+            claimed |= v[q];
+        }
+}
+
+__global__ __launch_bounds__(1024) void resolve_priority_kernel(uint64_t *__restrict__ rows, int64_t nw, int k,
+                                                                 const int32_t *__restrict__ size,
+                                                                 const uint64_t *__restrict__ keep,
+                                                                 int32_t *__restrict__ before, int32_t *__restrict__ after,
+                                                                 const int32_t *__restrict__ k_dev)
 {
     // k_dev != NULL: the row count lives on the device (groups formed there); k is then the capacity the launch
     // was sized for and a count beyond it leaves the rows alone (the host sees the count and takes the general path)
@@ -1771,80 +1749,50 @@ __global__ __launch_bounds__(64) void resolve_overlaps_kernel(uint64_t *__restri
         if (kd <= 0 || kd > k) return;
         k = kd;
     }
-    // before[i] = |row i| (P:592) = the diagonal of the intersections taken before any edit (when the pair masks came
-    // out of bff_cross_popcount_dev's epilogue instead of overlap_masks_kernel, which writes them too)
-    if (before && blockIdx.x == 0)
-        for (int r = threadIdx.x; r < k; r += kWave) before[r] = inter[(int64_t)r * stride + r];
-    constexpr int kPitch = kWave + 1;                        // column- and row-wise LDS accesses both conflict-free
-    __shared__ int s_size[kFuseMax];
-    // pair masks of the rows: in LDS for the word-column form (<= 256 rows x 4 words = 8 KB; one dependent global load per
-    // row made the 20-row scenes of the benchmark 2 x slower: 118 -> 190 us), straight from global memory for the
-    // half-word form, whose 512 columns x 65 x 4 B leave no room for 32 KB of masks
-    constexpr bool kMaskLds = sizeof(ColT) == 8;
-    constexpr int kMaskW = kFuseMax / 2 / 64;                // mask words of a row that can be non-zero in the word-column form
-    __shared__ unsigned long long s_mask[kMaskLds ? (kFuseMax / 2) * kMaskW : 1];
-    extern __shared__ uint64_t s_dyn[];
-    ColT *s_col = reinterpret_cast<ColT *>(s_dyn);           // [k][kPitch]
-    const int t = threadIdx.x;
-    ColT *rows = reinterpret_cast<ColT *>(rows64);
-    const ColT *keep = reinterpret_cast<const ColT *>(keep64);
-    const int64_t ncol = nw * (int64_t)(sizeof(uint64_t) / sizeof(ColT));      // columns of ColT per row
-    const int64_t w = (int64_t)blockIdx.x * kWave + t;
-    const int kw = (k + 63) / 64;
-    // independent loads, several in flight: the pair masks, the sizes, then this thread's column of every row
-    if (kMaskLds)
-        for (int q = t; q < k * kMaskW; q += kWave) s_mask[q] = pmask[(int64_t)(q / kMaskW) * kMW + (q % kMaskW)];
-    for (int r = t; r < k; r += kWave) s_size[r] = size[r];
+    extern __shared__ int s_res[];                                  // [k] sizes, then [k] rows by priority
+    int *s_size = s_res, *s_order = s_res + k;
+    __shared__ uint64_t s_seg[kResWaves][kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    for (int r = tid; r < k; r += 1024) s_size[r] = size[r];
+    __syncthreads();
+    for (int r = tid; r < k; r += 1024) {
+        const int sr = s_size[r];
+        int rank = 0;                                                // rows that take their points before row r does
 #pragma unroll 8
-    for (int r = 0; r < k; ++r) s_col[r * kPitch + t] = w < ncol ? rows[(int64_t)r * ncol + w] : 0;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // single wave: its LDS ops complete in order
-    // The reference's ordered pair loop (P:285-299) for this thread's column.  Row i stays in a register while its
-    // partners j > i are visited; their words are read eight at a time (independent LDS reads, one latency per batch
-    // instead of one read-modify-write round trip per pair), updated in registers in the reference's order, and the
-    // ones that changed are written back.
-    for (int i = 0; i < k; ++i) {
-        ColT acc = s_col[i * kPitch + t];
-        const int size_i = s_size[i];
-        bool touched = false;
-        for (int q = 0; q < kw; ++q) {
-            unsigned long long m = kMaskLds ? s_mask[i * kMaskW + q] : pmask[(int64_t)i * kMW + q];       // wave-uniform
-            while (m) {
-                int js[8];
-                ColT v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    js[e] = -1;
-                    if (m) { js[e] = 64 * q + __ffsll(m) - 1; m &= m - 1; }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = js[e] >= 0 ? s_col[js[e] * kPitch + t] : 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (js[e] >= 0) {                          // wave-uniform
-                        if (size_i > s_size[js[e]]) {          // i wins: j loses the current overlap (ties: i loses, P:296-299)
-                            v[e] &= ~acc;
-                            s_col[js[e] * kPitch + t] = v[e];
-                        } else {
-                            acc &= ~v[e];
-                            touched = true;
-                        }
-                    }
-            }
+        for (int q = 0; q < k; ++q) {
+            const int sq = s_size[q];
+            rank += (sq > sr || (sq == sr && q > r)) ? 1 : 0;
         }
-        if (touched) s_col[i * kPitch + t] = acc;
+        s_order[rank] = r;
     }
-    const ColT kp = keep ? (w < ncol ? keep[w] : 0) : (ColT)~(ColT)0;
-    for (int r = 0; r < k; ++r) {
-        const ColT v = s_col[r * kPitch + t] & kp;
-        s_col[r * kPitch + t] = v;
-        if (w < ncol) rows[(int64_t)r * ncol + w] = v;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int r = t; r < k; r += kWave) {                      // lane adds up rows r, r + 64, ... over the block's 64 columns
-        int pc = 0;
+    __syncthreads();
+    const int64_t w = (int64_t)blockIdx.x * kWave + lane;
+    const bool in = w < nw;
+    const uint64_t kp = keep ? (in ? keep[w] : 0) : ~0ull;
+    const int len = (k + kResWaves - 1) / kResWaves;                 // block-uniform
+    const int r0 = min(k, wave * len), r1 = min(k, r0 + len);
+    if (len <= 2) {
+        resolve_segment_in_registers<2>(rows, nw, w, in, r0, r1, s_order, s_seg, kp, before, after, lane, wave);
+    } else if (len <= 8) {
+        resolve_segment_in_registers<8>(rows, nw, w, in, r0, r1, s_order, s_seg, kp, before, after, lane, wave);
+    } else if (len <= 32) {
+        resolve_segment_in_registers<32>(rows, nw, w, in, r0, r1, s_order, s_seg, kp, before, after, lane, wave);
+    } else {
+        // more than 512 rows: two passes over the segment (the second one finds its words in the cache)
+        uint64_t tot = 0;
 #pragma unroll 8
-        for (int c = 0; c < kWave; ++c) pc += popc64((uint64_t)s_col[r * kPitch + c]);
-        if (pc) atomicAdd(after + r, pc);
+        for (int r = r0; r < r1; ++r) tot |= in ? rows[(int64_t)s_order[r] * nw + w] : 0;
+        s_seg[wave][lane] = tot;
+        __syncthreads();
+        uint64_t claimed = 0;
+        for (int s = 0; s < wave; ++s) claimed |= s_seg[s][lane];
+        for (int r = r0; r < r1; ++r) {
+            const int row = s_order[r];
+            uint64_t *dst = rows + (int64_t)row * nw + w;
+            const uint64_t v = in ? *dst : 0;
+            resolve_emit(dst, v, v & ~claimed & kp, in, row, before, after, lane);
+            claimed |= v;
+        }
     }
 }
 
@@ -1999,36 +1947,6 @@ __global__ void rle_lengths_kernel(int64_t *__restrict__ counts, int64_t n_runs_
 using namespace bff;
 
 // dynamic LDS beyond 64 KB has to be enabled per kernel once
-static int resolve_lds_attr(size_t bytes, const char *what)
-{
-    static size_t enabled = 0;
-    if (bytes <= enabled || bytes <= 64 * 1024) return BFF_OK;
-    constexpr size_t kMost = sizeof(uint64_t) * (kFuseMax / 2) * (kWave + 1);      // 256 rows of words = 512 rows of half words
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resolve_overlaps_kernel<uint64_t>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMost);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resolve_overlaps_kernel<uint32_t>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMost);
-    if (e != hipSuccess) return fail((int)e, "%s: LDS attribute: %s", what, hipGetErrorString(e));
-    enabled = kMost;
-    return BFF_OK;
-}
-
-// the fused overlap pass for k rows: word columns up to kFuseMax / 2 rows, half-word columns beyond (see the kernel)
-static void launch_resolve(uint64_t *rows, int64_t nw, int k, const uint64_t *pair_masks, const int32_t *size,
-                           const uint64_t *keep, int32_t *after, const int32_t *k_dev, const int32_t *inter, int stride,
-                           int32_t *before, hipStream_t st)
-{
-    const int64_t nwp = nw > 0 ? nw : 1;
-    if (k <= kFuseMax / 2)
-        resolve_overlaps_kernel<uint64_t><<<(unsigned)ceil_div(nwp, kWave), kWave, sizeof(uint64_t) * (size_t)k * (kWave + 1), st>>>(
-            rows, nw, k, (const unsigned long long *)pair_masks, size, keep, after, k_dev, inter, stride, before);
-    else
-        resolve_overlaps_kernel<uint32_t><<<(unsigned)ceil_div(2 * nwp, kWave), kWave, sizeof(uint32_t) * (size_t)k * (kWave + 1), st>>>(
-            rows, nw, k, (const unsigned long long *)pair_masks, size, keep, after, k_dev, inter, stride, before);
-}
-#define BFF_TRY_LDS(bytes, what) do { const int rc_ = resolve_lds_attr((bytes), (what)); if (rc_ != BFF_OK) return rc_; } while (0)
-
 extern "C" int bff_popcount_rows(const uint64_t *rows, const int32_t *idx, int32_t n_rows, int64_t nw,
                                  int32_t *area, void *stream)
 {
@@ -2057,20 +1975,18 @@ extern "C" int bff_cross_popcount(const uint64_t *a, const int32_t *ia, int32_t 
         if (e != hipSuccess) return fail((int)e, "bff_cross_popcount: memset: %s", hipGetErrorString(e));
     }
     dim3 grid((unsigned)ceil_div(nb, kT), (unsigned)ceil_div(na, kT), (unsigned)nz);
-    cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, ia, na, b, ib, nb, nw, k_split, inter, nullptr, 0, 0, nullptr);
+    cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, ia, na, b, ib, nb, nw, k_split, inter, nullptr, 0, 0);
     return launched("bff_cross_popcount");
 }
 
 // bff_cross_popcount where only the first *k_dev rows of the leading `lead` rows of b (and, with limit_a != 0, of a)
 // are non-zero: tiles inside the zero part are skipped.  inter is zeroed first.
 extern "C" int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint64_t *b, int32_t nb, int64_t nw,
-                                      int32_t *inter, const int32_t *k_dev, int32_t limit_a, int32_t lead,
-                                      uint64_t *pair_masks, void *stream)
+                                      int32_t *inter, const int32_t *k_dev, int32_t limit_a, int32_t lead, void *stream)
 {
     BFF_REQUIRE(na >= 0 && nb >= 0 && nw >= 0 && lead >= 0 && lead <= nb, "bff_cross_popcount_dev: bad sizes");
     if (na == 0 || nb == 0) return BFF_OK;
     BFF_REQUIRE(a && b && inter && k_dev, "bff_cross_popcount_dev: null pointer");
-    BFF_REQUIRE(!pair_masks || (a == b && na == nb && na <= kFuseMax), "bff_cross_popcount_dev: pair masks need a == b, <= %d rows", kFuseMax);
     const int64_t tiles = ceil_div(nb, kT) * ceil_div(na, kT);
     int64_t k_split = nw;
     if (tiles < 512) {
@@ -2079,11 +1995,10 @@ extern "C" int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint6
     }
     const int64_t nz = ceil_div(nw, k_split);
     hipError_t e = zero_async(inter, sizeof(int32_t) * (size_t)na * nb, as_stream(stream));
-    if (e == hipSuccess && pair_masks) e = zero_async(pair_masks, sizeof(uint64_t) * (size_t)kFuseMax * kMW, as_stream(stream));
     if (e != hipSuccess) return fail((int)e, "bff_cross_popcount_dev: memset: %s", hipGetErrorString(e));
     dim3 grid((unsigned)ceil_div(nb, kT), (unsigned)ceil_div(na, kT), (unsigned)(nz > 0 ? nz : 1));
     cross_popcount_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, nullptr, na, b, nullptr, nb, nw, k_split, inter, k_dev,
-                                                              limit_a, lead, (unsigned long long *)pair_masks);
+                                                              limit_a, lead);
     return launched("bff_cross_popcount_dev");
 }
 
@@ -2398,46 +2313,37 @@ extern "C" int bff_overlap_ops(const int32_t *inter, const int32_t *size, int32_
     return launched("bff_overlap_ops");
 }
 
-// pair masks live in a small device scratch owned by the library (kFuseMax x 4 words per stream slot is tiny, but a
-// global buffer would race between streams): the callers pass one, see bff_hip.h
-extern "C" int64_t bff_resolve_overlaps_scratch_words(void) { return (int64_t)kFuseMax * kMW; }
+static int launch_resolve(uint64_t *rows, int k, int64_t nw, const int32_t *size, const uint64_t *keep, int32_t *before,
+                          int32_t *after, const int32_t *k_dev, hipStream_t st, const char *what)
+{
+    hipError_t e = zero_async(before, sizeof(int32_t) * (size_t)k, st);
+    if (e == hipSuccess) e = zero_async(after, sizeof(int32_t) * (size_t)k, st);
+    if (e != hipSuccess) return fail((int)e, "%s: memset: %s", what, hipGetErrorString(e));
+    resolve_priority_kernel<<<(unsigned)ceil_div(nw > 0 ? nw : 1, kWave), 1024, sizeof(int) * 2 * (size_t)k, st>>>(
+        rows, nw, k, size, keep, before, after, k_dev);
+    return launched(what);
+}
 
-extern "C" int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const int32_t *inter, const int32_t *size,
-                                    const uint64_t *keep, int32_t *before, int32_t *after, uint64_t *pair_masks,
-                                    void *stream)
+extern "C" int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const int32_t *size, const uint64_t *keep,
+                                    int32_t *before, int32_t *after, void *stream)
 {
     BFF_REQUIRE(k >= 0 && nw >= 0, "bff_resolve_overlaps: bad sizes");
-    BFF_LIMIT(k <= kFuseMax, "bff_resolve_overlaps: more than %d rows (use bff_overlap_ops + bff_apply_row_ops)", kFuseMax);
+    BFF_LIMIT(k <= kResolveMax, "bff_resolve_overlaps: more than %d rows (use bff_overlap_ops + bff_apply_row_ops)", kResolveMax);
     if (k == 0) return BFF_OK;
-    BFF_REQUIRE(rows && inter && size && before && after && pair_masks, "bff_resolve_overlaps: null pointer");
-    hipError_t e = hipMemsetAsync(after, 0, sizeof(int32_t) * (size_t)k, as_stream(stream));
-    if (e != hipSuccess) return fail((int)e, "bff_resolve_overlaps: memset: %s", hipGetErrorString(e));
-    overlap_masks_kernel<<<(unsigned)ceil_div(k, 4), 256, 0, as_stream(stream)>>>(inter, k, k, nullptr,
-                                                                                (unsigned long long *)pair_masks, before);
-    BFF_TRY_LDS((k <= kFuseMax / 2 ? sizeof(uint64_t) : sizeof(uint32_t)) * (size_t)k * (kWave + 1), "bff_resolve_overlaps");
-    launch_resolve(rows, nw, k, pair_masks, size, keep, after, nullptr, nullptr, 0, nullptr, as_stream(stream));
-    return launched("bff_resolve_overlaps");
+    BFF_REQUIRE(rows && size && before && after, "bff_resolve_overlaps: null pointer");
+    return launch_resolve(rows, k, nw, size, keep, before, after, nullptr, as_stream(stream), "bff_resolve_overlaps");
 }
 
-extern "C" int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *inter,
-                                        const int32_t *size, const uint64_t *keep, int32_t *before, int32_t *after,
-                                        uint64_t *pair_masks, int32_t masks_ready, const int32_t *k_dev, void *stream)
+extern "C" int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *size, const uint64_t *keep,
+                                        int32_t *before, int32_t *after, const int32_t *k_dev, void *stream)
 {
     BFF_REQUIRE(k_cap > 0 && nw >= 0, "bff_resolve_overlaps_dev: bad sizes");
-    BFF_LIMIT(k_cap <= kFuseMax, "bff_resolve_overlaps_dev: capacity beyond %d rows", kFuseMax);
-    BFF_REQUIRE(rows && inter && size && before && after && k_dev && pair_masks, "bff_resolve_overlaps_dev: null pointer");
-    hipError_t e = zero_async(after, sizeof(int32_t) * (size_t)k_cap, as_stream(stream));
-    if (e != hipSuccess) return fail((int)e, "bff_resolve_overlaps_dev: memset: %s", hipGetErrorString(e));
-    if (!masks_ready)           // masks_ready: bff_cross_popcount_dev(..., pair_masks) built them with the intersections
-        overlap_masks_kernel<<<(unsigned)ceil_div(k_cap, 4), 256, 0, as_stream(stream)>>>(inter, k_cap, k_cap, k_dev,
-                                                                                        (unsigned long long *)pair_masks, before);
-    BFF_TRY_LDS((k_cap <= kFuseMax / 2 ? sizeof(uint64_t) : sizeof(uint32_t)) * (size_t)k_cap * (kWave + 1), "bff_resolve_overlaps_dev");
-    launch_resolve(rows, nw, k_cap, pair_masks, size, keep, after, k_dev, inter, k_cap, masks_ready ? before : nullptr,
-                   as_stream(stream));
-    return launched("bff_resolve_overlaps_dev");
+    BFF_LIMIT(k_cap <= kResolveMax, "bff_resolve_overlaps_dev: capacity beyond %d rows", kResolveMax);
+    BFF_REQUIRE(rows && size && before && after && k_dev, "bff_resolve_overlaps_dev: null pointer");
+    return launch_resolve(rows, k_cap, nw, size, keep, before, after, k_dev, as_stream(stream), "bff_resolve_overlaps_dev");
 }
 
-extern "C" int bff_resolve_overlaps_max_rows(void) { return kFuseMax; }
+extern "C" int bff_resolve_overlaps_max_rows(void) { return kResolveMax; }
 
 extern "C" int bff_apply_row_ops(uint64_t *rows, int64_t nw, const int32_t *ops, int32_t n_ops, void *stream)
 {

@@ -69,7 +69,7 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
         if (e != hipSuccess) return fail((int)e, "bff_scene_project: memset: %s", hipGetErrorString(e)); } while (0)
 
     // ONE fill clears every scratch buffer of the call: counters, chunk flags, segment bitmap, header, merge lists and
-    // split slots, intersections, pair masks, the OR targets (bff_scene_workspace lays them out in one block); the steps'
+    // split slots, the OR targets (bff_scene_workspace lays them out in one block); the steps'
     // own clears are switched off for the duration of the call
     BFF_REQUIRE(ws->zero_bytes > 0 && ws->masked, "bff_scene_project: no zero block");
     {
@@ -84,9 +84,8 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
                     inside(ws->count, sizeof(int32_t) * (size_t)n_rows) &&
                     inside(ws->chunk_mask, sizeof(uint64_t) * (size_t)n_rows * mw) && inside(ws->segmap, seg_bytes) &&
                     inside(hdr, sizeof(int32_t) * (size_t)bff_scene_header_words(sc->s1_rows, cap)) &&
-                    inside(ws->inter, sizeof(int32_t) * (size_t)cap * cap) && inside(ws->agg, sizeof(uint64_t) * (size_t)cap * nw) &&
+                    inside(ws->agg, sizeof(uint64_t) * (size_t)cap * nw) &&
                     inside(ws->merge_scratch, sizeof(uint32_t) * (size_t)bff_merge_scratch_words(n_rows)) &&
-                    inside(ws->pair_masks, sizeof(uint64_t) * (size_t)bff_resolve_overlaps_scratch_words()) &&
                     (!use_cpop || inside(ws->chunk_pop, sizeof(uint16_t) * (size_t)n_rows * mw * 64)),
                     "bff_scene_project: a scratch buffer lies outside the zero block (workspace layout)");
     }
@@ -172,11 +171,9 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     // last reader of the raw rows is done: give the arena its zeros back -- unless the host has to take the general
     // path (more groups than the device forms), which reads the rows again and clears them itself
     BFF_TRY(bff_clear_flagged_chunks_unless(ws->rows, n_rows, nw, ws->chunk_mask, info + 1, stream));
-    // a16 + P:592-596: intersections before any edit (their epilogue leaves the pair flags of P:289-292), ordered
-    // overlap decisions, &= keep, both popcounts
-    BFF_TRY(bff_cross_popcount_dev(ws->agg, cap, ws->agg, cap, nw, ws->inter, info, 2, cap, ws->pair_masks, stream));
-    BFF_TRY(bff_resolve_overlaps_dev(ws->agg, cap, nw, ws->inter, hdr + BFF_HDR_SIZES(cap), ws->keep, hdr + BFF_HDR_BEFORE(cap),
-                                     hdr + BFF_HDR_AFTER(cap), ws->pair_masks, 1, info, stream));
+    // a16 + P:592-596: overlap decisions (one prefix OR in priority order), &= keep, both popcounts
+    BFF_TRY(bff_resolve_overlaps_dev(ws->agg, cap, nw, hdr + BFF_HDR_SIZES(cap), ws->keep, hdr + BFF_HDR_BEFORE(cap),
+                                     hdr + BFF_HDR_AFTER(cap), info, stream));
     // caller's point order (scatter of the set bits); the refinement's first device pass (R:186-217) rides along when
     // stage 1 is resident.  `both` is the caller's buffer (it outlives the workspace's reuse): its clear is the one
     // fill besides the block's
@@ -191,7 +188,7 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
         uint64_t *s1 = ws->both + (size_t)cap * nw;
         BFF_TRY(bff_rle_to_rows(sc->s1_run_start, sc->s1_run_end, sc->s1_row_run_offs, sc->s1_rows, n, nw, s1, stream));
         BFF_TRY(bff_cross_popcount_dev(s1, sc->s1_rows, ws->both, cap + sc->s1_rows, nw, hdr + BFF_HDR_CROSS(cap), info, 0, cap,
-                                       nullptr, stream));
+                                       stream));
     }
     e = hipMemcpyAsync(ws->hdr_host, hdr, sizeof(int32_t) * (size_t)bff_scene_header_words(sc->s1_rows, cap),
                        hipMemcpyDeviceToHost, st);

@@ -49,7 +49,7 @@ class ParamsStruct(ctypes.Structure):
 
 _WS_PTRS = ["maskbits", "segmap", "labels", "rows", "chunk_mask", "keep", "tile_mask", "agg", "both",
             "masked", "viewed", "sel_scratch", "area", "mean_word", "order", "parent", "comp", "count",
-            "gmembers", "goffs", "slices", "inter", "pair_masks", "pair_scratch", "vals", "vals_sorted", "hist", "merge_scratch", "chunk_pop",
+            "gmembers", "goffs", "slices", "pair_scratch", "vals", "vals_sorted", "hist", "merge_scratch", "chunk_pop",
             "sig", "sig_keys", "sig_sorted", "sort_temp"]
 
 
@@ -239,7 +239,6 @@ class SceneWorkspace:
         use_cpop = bool(lib.bff_merge_uses_chunk_bound(nw))
         parts = [("masked", 4 * n, i32), ("viewed", 4 * n, i32), ("count", 4 * n_rows, i32),
                  ("chunk_mask", 8 * n_rows * mw, i64), ("segmap", 4 * seg_words, i32), ("hdr", 4 * hdr_words, i32),
-                 ("inter", 4 * cap * cap, i32), ("pair_masks", 8 * int(lib.bff_resolve_overlaps_scratch_words()), i64),
                  ("agg", 8 * cap * nw, i64), ("merge_scratch", 4 * int(lib.bff_merge_scratch_words(n_rows)), i32)]
         if use_cpop:
             parts.append(("chunk_pop", 2 * n_rows * mw * 64, torch.int16))

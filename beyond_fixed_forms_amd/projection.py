@@ -467,18 +467,9 @@ def _projection_back(fr: _Front, timers, phases, stage1=None) -> Stage2Result:
     mark("grouping+or_reduce")
 
     # a16: overlap resolution (P:592-596), decided and applied on the device
-    if size_list is None:
-        before, after = _lib.resolve_overlaps_filtered(agg, sizes_d, keep)           # P:592-596
-    else:           # sizes indexed like mask_indeces_to_be_merged, which still holds the empty components
-        before = _lib.popcount_rows(agg)                                            # P:592
-        inter = _lib.cross_popcount(agg, agg).cpu().numpy()
-        k = agg.shape[0]
-        ops = [(0, j, i) if size_list[i] > size_list[j] else (0, i, j)
-               for i in range(k) for j in range(i + 1, k) if inter[i, j] > 0]
-        if ops:
-            _lib.apply_row_ops(agg, _lib.upload(np.asarray(ops, dtype=np.int32), torch.int32, dev))
-        _lib.and_rows(agg, keep)                                                    # P:595
-        after = _lib.popcount_rows(agg)                                             # P:596
+    if size_list is not None:   # sizes indexed like mask_indeces_to_be_merged, which still holds the empty components (P:285)
+        sizes_d = _lib.upload(np.asarray(size_list[:agg.shape[0]], dtype=np.int32), torch.int32, dev)
+    before, after = _lib.resolve_overlaps_filtered(agg, sizes_d, keep)               # P:592-596
     mark("overlap")
 
     # a17: size filters with the reference's dtype promotion (int64 vs python scalars, P:601-606)

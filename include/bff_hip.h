@@ -32,7 +32,7 @@ extern "C" {
 #define BFF_E_ARG (-1)      /* null pointer / negative size / unsupported parameter */
 #define BFF_E_LIMIT (-2)    /* size beyond what a kernel supports (documented per call) */
 
-#define BFF_ABI_VERSION 5
+#define BFF_ABI_VERSION 6
 
 int bff_abi_version(void);
 const char *bff_last_error(void);
@@ -302,16 +302,17 @@ int bff_or_reduce_groups(const uint64_t *rows, int64_t nw, const int32_t *group_
 int bff_group_conf_mean(const void *conf, int32_t dtype, const int32_t *group_offs, const int32_t *members,
                         int32_t n_groups, void *mean, void *stream);
 
-/* a16 + a14 + the two popcounts around them, fused for k <= bff_resolve_overlaps_max_rows() (256) rows:
- *   before[i] = inter[i][i]                                   (row popcounts before any edit, P:592)
- *   solve_overlapping P:285-299 on `rows` in place: pairs (i < j) with inter[i][j] > 0 in the reference's order,
- *     the row merged from fewer raw masks (size[], ties: row i) loses the points of the other;
+/* a16 + a14 + the two popcounts around them in one pass, k <= bff_resolve_overlaps_max_rows() (4096) rows:
+ *   before[i] = popcount(rows[i])                             (before any edit, P:592)
+ *   solve_overlapping P:277-301 on `rows` in place.  The reference visits the pairs (i < j) that overlap before any
+ *     edit in (i, j) order; the row merged from fewer raw masks (size[], ties: row i) loses the points of the other.
+ *     For a single point that walk is a champion scan over the rows holding it, so the point ends up in exactly one of
+ *     them: the one with the largest size, among equals the largest index (derivation: rows.hip,
+ *     resolve_priority_kernel) -- an exclusive prefix OR over the rows in that order, no intersections needed;
  *   rows[i] &= keep (P:595; keep may be NULL);  after[i] = popcount(rows[i])  (P:596).
- * inter = bff_cross_popcount(rows, rows) taken BEFORE the call (int32 [k][k]). */
-int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const int32_t *inter, const int32_t *size,
-                         const uint64_t *keep, int32_t *before, int32_t *after, uint64_t *pair_masks, void *stream);
-/* pair_masks: device scratch, uint64 [bff_resolve_overlaps_scratch_words()] (the pair flags of P:289-292 as bit masks). */
-int64_t bff_resolve_overlaps_scratch_words(void);
+ * The literal ordered replay stays available as bff_overlap_ops + bff_apply_row_ops (tests compare the two). */
+int bff_resolve_overlaps(uint64_t *rows, int32_t k, int64_t nw, const int32_t *size, const uint64_t *keep,
+                         int32_t *before, int32_t *after, void *stream);
 int bff_resolve_overlaps_max_rows(void);
 
 /* a16/a20: sequential row program applied independently to every word column.
@@ -467,23 +468,17 @@ int bff_group_components(int32_t *comp, int32_t *parent, const int32_t *area, in
 int bff_or_reduce_grouped(const uint64_t *rows, int64_t nw, int32_t n_rows, const int32_t *info, int32_t cap,
                           const int32_t *offs, const int32_t *members, const int32_t *slices, uint64_t *out,
                           const void *conf, int32_t conf_dtype, void *conf_mean, const uint64_t *chunk_mask, void *stream);
-/* bff_resolve_overlaps with the row count on the device (*k_dev <= k_cap, else nothing is touched); inter is
- * [k_cap][k_cap].  masks_ready != 0: pair_masks were built by bff_cross_popcount_dev together with `inter` (one launch
- * less); `before` is then read off the diagonal of `inter` inside the overlap pass. */
-int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *inter, const int32_t *size,
-                             const uint64_t *keep, int32_t *before, int32_t *after, uint64_t *pair_masks,
-                             int32_t masks_ready, const int32_t *k_dev, void *stream);
+/* bff_resolve_overlaps with the row count on the device (*k_dev <= k_cap, else nothing is touched). */
+int bff_resolve_overlaps_dev(uint64_t *rows, int32_t k_cap, int64_t nw, const int32_t *size, const uint64_t *keep,
+                             int32_t *before, int32_t *after, const int32_t *k_dev, void *stream);
 /* out[r] bit perm[s] = in[r] bit s, set bits only (undoes the spatial point sort by scatter: aggregated rows are
  * sparse); out must be zero; rows >= *k_dev (when given) are skipped. */
 int bff_scatter_bits(const uint64_t *rows_in, int32_t n_rows, int64_t nw_in, const int32_t *perm, int64_t n,
                      int64_t nw_out, uint64_t *rows_out, const int32_t *k_dev, void *stream);
 /* bff_cross_popcount when only the first *k_dev rows of b's leading `lead` rows (and of a, with limit_a) are
- * non-zero: tiles inside the zero part are skipped; inter is zeroed first.  limit_a == 2: a and b are the same rows and
- * only entries inter[i][j] with j >= i (up to tile granularity) are needed.  pair_masks (optional; a == b, at most
- * BFF_GROUP_CAP_MAX rows): also writes the pair flags of solve_overlapping (P:289-292) -- bit j of row i's
- * BFF_GROUP_CAP_MAX / 64 words = rows j > i that overlap row i -- for bff_resolve_overlaps_dev(masks_ready = 1). */
+ * non-zero: tiles inside the zero part are skipped; inter is zeroed first. */
 int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint64_t *b, int32_t nb, int64_t nw, int32_t *inter,
-                           const int32_t *k_dev, int32_t limit_a, int32_t lead, uint64_t *pair_masks, void *stream);
+                           const int32_t *k_dev, int32_t limit_a, int32_t lead, void *stream);
 /* bff_clear_flagged_chunks unless *veto != 0 (device flag). */
 int bff_clear_flagged_chunks_unless(uint64_t *rows, int32_t n_rows, int64_t nw, const uint64_t *chunk_mask,
                                     const int32_t *veto, void *stream);
@@ -519,16 +514,15 @@ typedef struct bff_scene_params {
 
 /* Scratch of bff_scene_project, allocated by the caller for the scene's sizes (beyond_fixed_forms_amd/pipeline.py).
  * `rows` must be all zero on entry; it is all zero again when the call's work has run on the fast path.
- * Every buffer the call's steps expect zeroed -- masked, viewed, count, chunk_mask, segmap, hdr, inter, agg, merge_scratch,
- * pair_masks and (clouds that use the chunk bound) chunk_pop -- must lie inside ONE allocation of `zero_bytes` bytes
+ * Every buffer the call's steps expect zeroed -- masked, viewed, count, chunk_mask, segmap, hdr, agg, merge_scratch
+ * and (clouds that use the chunk bound) chunk_pop -- must lie inside ONE allocation of `zero_bytes` bytes
  * starting at `masked`: the call clears it with a single fill (checked; beyond_fixed_forms_amd/pipeline.py lays it out). */
 typedef struct bff_scene_workspace {
     void *maskbits; uint32_t *segmap;  /* word plane and two-word segment bitmap of bff_rle_to_labels */
     uint8_t *labels;                /* palette blocks, [n_mviews][bff_label_plane_stride(H*W)] */
     uint64_t *rows, *chunk_mask, *keep, *tile_mask, *agg, *both;
     int32_t *masked, *viewed, *sel_scratch, *area, *mean_word, *order, *parent, *comp, *count;
-    int32_t *gmembers, *goffs, *slices, *inter;
-    uint64_t *pair_masks;           /* bff_resolve_overlaps_scratch_words() */
+    int32_t *gmembers, *goffs, *slices;
     uint32_t *pair_scratch;         /* bff_point_threshold_scratch_words(n_points) */
     float *vals, *vals_sorted;
     uint32_t *hist, *merge_scratch;
@@ -538,7 +532,7 @@ typedef struct bff_scene_workspace {
     size_t zero_bytes;              /* size of the block that starts at `masked` (see above) */
     int32_t *hdr;                   /* device, bff_scene_header_words(s1_rows, group_cap) int32 */
     int32_t *hdr_host;              /* pinned host mirror of the same size */
-    int32_t group_cap;              /* BFF_GROUP_CAP or BFF_GROUP_CAP_MAX: kept groups formed on the device; agg, inter, both and the
+    int32_t group_cap;              /* BFF_GROUP_CAP or BFF_GROUP_CAP_MAX: kept groups formed on the device; agg, both and the
                                        header are sized by it.  More groups than that: header flag, the host continues */
     int32_t pad_;
     void *heavy_stream;             /* optional hipStream_t for the chip-filling kernels (decode, sweep, tile pass): callers that keep

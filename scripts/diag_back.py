@@ -32,7 +32,7 @@ agg = d.clone()
 sizes_d = torch.from_numpy(sizes).to(dev)
 timeit("popcount_rows(agg)", lambda: _lib.popcount_rows(agg))
 timeit("cross_popcount(agg, agg)", lambda: _lib.cross_popcount(agg, agg))
-timeit("resolve_overlaps (3 launches)", lambda: _lib.resolve_overlaps(agg.clone(), sizes_d))
-timeit("resolve_overlaps_filtered (2)", lambda: _lib.resolve_overlaps_filtered(agg.clone(), sizes_d, fr.keep))
+timeit("resolve_overlaps, ordered replay (3 launches)", lambda: _lib.resolve_overlaps_replay(agg.clone(), sizes_d))
+timeit("resolve_overlaps_filtered (1 launch)", lambda: _lib.resolve_overlaps_filtered(agg.clone(), sizes_d, fr.keep))
 timeit("  (clone alone)", lambda: agg.clone())
 timeit("and_rows", lambda: _lib.and_rows(agg, fr.keep))

@@ -463,7 +463,7 @@ def test_resolve_overlaps_golden(lib):
         lib.resolve_overlaps(rows, torch.tensor(z[f"{case}.sizes"], dtype=torch.int32, device=DEV))
         assert np.array_equal(unpack(rows, n), gio.unpack_bool_rows(z[f"{case}.resolved"], n)), case
     rng = np.random.default_rng(9)
-    for k, p in ((23, 0.15), (110, 0.01)):         # 110 > 96 rows: the pair loop reads global memory
+    for k, p in ((23, 0.15), (110, 0.01), (140, 0.2)):         # segments of 2, 7, 9 rows per wave
         d = rng.random((k, 3000)) < p
         sizes = rng.integers(2, 6, k)
         exp = pref.resolve_overlaps(torch.from_numpy(d.copy()), [list(range(s)) for s in sizes]).numpy()
@@ -472,22 +472,30 @@ def test_resolve_overlaps_golden(lib):
         assert np.array_equal(unpack(rows, 3000), exp)
 
 
-@pytest.mark.parametrize("k,n", [(1, 100), (2, 64), (17, 5000), (64, 777), (70, 3000), (200, 4100), (256, 500), (300, 900)])
-def test_resolve_overlaps_filtered_equals_separate_steps(lib, k, n):
-    """Fused pass (k <= 256: pair masks of up to four 64-bit words) and the fallback (k = 300) == popcount,
-    resolve_overlaps, and_rows, popcount."""
+@pytest.mark.parametrize("k,n,p", [(1, 100, 0.1), (2, 64, 0.5), (17, 5000, 0.08), (33, 777, 0.6), (64, 777, 0.08), (129, 3000, 0.3),
+                                   (200, 4100, 0.08), (512, 500, 0.05), (513, 900, 0.08), (1500, 700, 0.02), (4200, 300, 0.01)])
+def test_resolve_overlaps_closed_form_equals_the_ordered_replay(lib, k, n, p):
+    """One pass (every point stays in the row with the largest size, ties: the largest index -- a prefix OR in that order)
+    == the reference's loop spelled out: popcount, the ordered pair list of P:289-292 replayed pair by pair (P:295-299),
+    and_rows, popcount.  Segment lengths 1 .. 32 rows per wave, the two-pass form (k > 512) and the replay fallback
+    (k > bff_resolve_overlaps_max_rows()); many size ties."""
     rng = np.random.default_rng(k)
-    d = random_rows(rng, k, n, 0.08)
+    d = random_rows(rng, k, n, p)
     keep = pack_np(rng.random((1, n)) < 0.7)[0]
-    sizes = torch.from_numpy(rng.integers(1, 6, k).astype(np.int32)).to(DEV)        # many ties
+    sizes = torch.from_numpy(rng.integers(1, 6, k).astype(np.int32)).to(DEV)
     ref = pack_np(d)
     before_ref = lib.popcount_rows(ref)
-    lib.resolve_overlaps(ref, sizes)
+    lib.resolve_overlaps_replay(ref, sizes)
     lib.and_rows(ref, keep)
     after_ref = lib.popcount_rows(ref)
     rows = pack_np(d)
     before, after = lib.resolve_overlaps_filtered(rows, sizes, keep)
     assert torch.equal(rows, ref) and torch.equal(before, before_ref) and torch.equal(after, after_ref)
+    if k <= 300:        # and without a filter, against the oracle's loop
+        exp = pref.resolve_overlaps(torch.from_numpy(d.copy()), [list(range(s)) for s in sizes.tolist()]).numpy()
+        rows = pack_np(d)
+        lib.resolve_overlaps(rows, sizes)
+        assert np.array_equal(unpack(rows, n), exp)
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 128, 10_001, 16_384 + 64, 200_000])

@@ -40,8 +40,8 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
 
 
 def test_size_limits_are_rejected_on_the_host():
-    """Maximum sizes (DESIGN: 2^31 pixels per image, 4096 row chunks = 2.1 M points per call, 64 rows for the fused
-    overlap pass): beyond them every entry point answers BFF_E_LIMIT before touching the GPU."""
+    """Maximum sizes (DESIGN: 2^31 pixels per image, 4096 row chunks = 2.1 M points per call, 4096 rows for the
+    one-pass overlap resolution): beyond them every entry point answers BFF_E_LIMIT before touching the GPU."""
     import ctypes
     from beyond_fixed_forms_amd import _lib
     lib = _lib.load()
@@ -50,8 +50,8 @@ def test_size_limits_are_rejected_on_the_host():
     too_many_words = 8 * 4096 + 8
     assert lib.bff_row_stats(p, 1, too_many_words, p, p, p, 0, p, p, None, None) == -2 and b"4096 chunks" in lib.bff_last_error()
     assert lib.bff_merge_components(p, 64, too_many_words, None, 64, p, p, p, p, p, p, 0.2, p, 1, p, None, None, None) == -2
-    assert lib.bff_resolve_overlaps(p, 513, 10, p, p, None, p, p, p, None) == -2 and b"512 rows" in lib.bff_last_error()
-    assert lib.bff_resolve_overlaps_max_rows() == 512
+    assert lib.bff_resolve_overlaps(p, 4097, 10, p, None, p, p, None) == -2 and b"4096 rows" in lib.bff_last_error()
+    assert lib.bff_resolve_overlaps_max_rows() == 4096
     assert lib.bff_rle_to_maskbits(p, p, p, p, 1, 1 << 31, 32, p, None, None) == -2
     assert lib.bff_rle_to_labels(p, p, p, p, 1, 1 << 31, 32, p, p, None, None) == -2
     assert lib.bff_rle_to_labels(p, p, p, p, 1, 100, 32, None, p, None, None) == -1

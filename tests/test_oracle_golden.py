@@ -174,3 +174,23 @@ def test_evaluation_assignment_restatement(name):
     preds, sem, ins, use_label, exp = gio.eval_case(z, name)
     gt2pred, pred2gt = assign_instances_ref(preds, sem, ins, labels, use_label=use_label)
     gio.same_assignment(flatten_assignment(gt2pred, pred2gt, labels if use_label else ["class_agnostic"]), exp)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_ordered_overlap_loop_has_a_closed_form(seed):
+    """What the device's one-pass overlap resolution relies on (rows.hip, resolve_priority_kernel): after the reference's
+    ordered pair loop (P:277-301) every point that was in some row is in exactly one of them -- the one merged from the most
+    raw masks, among equals the one with the LARGEST index.  Checked here against the oracle's literal loop: random
+    rows from sparse to nearly full, sizes with many ties, also all sizes equal and strictly increasing / decreasing."""
+    rng = np.random.default_rng(seed)
+    k, n = int(rng.integers(1, 40)), int(rng.integers(1, 300))
+    d = rng.random((k, n)) < rng.choice([0.02, 0.2, 0.6, 0.95])
+    sizes = {0: np.full(k, 3), 1: np.arange(k) + 1, 2: np.arange(k)[::-1] + 1}.get(seed % 4, rng.integers(1, 5, k))
+    got = pref.resolve_overlaps(torch.from_numpy(d.copy()), [list(range(int(s))) for s in sizes]).numpy()
+    # priority: size, then index; a point goes to the best row that holds it
+    prio = sizes.astype(np.int64) * (k + 1) + np.arange(k)
+    best = np.where(d, prio[:, None], -1).argmax(axis=0)
+    exp = np.zeros_like(d)
+    cols = np.nonzero(d.any(axis=0))[0]
+    exp[best[cols], cols] = True
+    assert np.array_equal(got, exp)
