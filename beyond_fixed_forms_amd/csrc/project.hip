@@ -478,16 +478,28 @@ __global__ __launch_bounds__(kBlock) void point_tile_bounds_kernel(const double 
 }
 
 // ---------------------------------------------------------------------------------------------
-// 2-D RLE -> mask words, wave-synchronous.  Every wave owns a band of kWaveChunks x 512 pixels of one
+// 2-D RLE -> mask words, wave-synchronous.  Every wave owns a band of kWaveChunks x 1024 pixels of one
 // mask-view and a private 1024-word LDS slice; lane b < n_masks keeps mask b's run cursor (current + next
-// run in registers).  Per 1024-pixel chunk the runs enter LDS as XOR toggles at their clipped start and end,
-// an XOR prefix scan (4 words per lane in each of 4 sub-blocks, DPP wave scans) turns toggles into coverage, and
-// the chunk is written with four fully coalesced 1-KiB (u32) stores.  There is no block barrier: waves never wait for each
-// other, LDS accesses of one wave complete in issue order.  Segments of 128 pixels without any mask pixel
-// are not written when a segment bitmap is requested.  HBM traffic = at most one write of the image.
-constexpr int kSub = 4;                      // 256-word sub-blocks per chunk; a lane owns 4 consecutive words of each
-constexpr int kWaveChunk = kSub * 256;       // pixels per wave chunk
+// run in registers).  Per 1024-pixel chunk the runs enter LDS as XOR toggles at their clipped start and end; then
+// every lane takes 16 CONSECUTIVE pixels: an XOR prefix over its toggles, one wave scan of the lanes' totals (DPP), and
+// the lane holds its 16 mask words.  There is no block barrier: waves never wait for each other, LDS accesses of one
+// wave complete in issue order.  Segments of 128 pixels (8 lanes) without any mask pixel are not written when a
+// segment bitmap is requested.  HBM traffic = at most one write of the image.
+//
+// The kernel is bound by its VALU instructions (a wave64 instruction occupies a SIMD for four cycles): with 4 pixels
+// per lane and four wave scans per chunk it spent ~22 instructions per pixel (0.21 ms at config 2); 16 pixels per
+// lane need one wave scan and one segmented scan per chunk, and the piece numbers of 8 pixels are one 32-bit SWAR
+// prefix sum.
+constexpr int kWaveChunk = 1024;             // pixels per wave chunk
+constexpr int kPx = kWaveChunk / kWave;      // consecutive pixels per lane; a 128-pixel segment is 8 lanes
 constexpr int kWaveChunks = 16384 / kWaveChunk;   // chunks per wave band (16384 pixels)
+
+// LDS position of chunk word i.  A lane moves its 16 consecutive words with four 16-byte accesses 64 bytes apart: left
+// in place, the lanes of an access group (16 lanes for ds_read_b128 over 64 banks, 8 contiguous lanes for ds_write_b128
+// over 32) would meet on the same banks four at a time.  XOR-ing slot bits (i >> 2) with lane bits -- slot bits 0-1
+// with lane bits 1-2, slot bit 3 with lane bit 3 -- spreads every group over all banks; the four words of a 16-byte
+// slot stay together, so the coalesced word-form read-out (lane l: words 4l..4l+3 of a 256-word block) still moves slots.
+__device__ __forceinline__ int chunk_word_slot(int i) { return i ^ ((((i >> 5) & 3) | ((i >> 4) & 8)) << 2); }
 
 // Inclusive XOR prefix over the 64 lanes of a wave in six DPP steps (row shifts 1, 2, 4, 8 inside each 16-lane
 // row, then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2-3): register-to-register, no LDS
@@ -510,6 +522,32 @@ __device__ __forceinline__ uint64_t wave_xor_scan(uint64_t v)
     return (uint64_t)wave_xor_scan((uint32_t)v) | ((uint64_t)wave_xor_scan((uint32_t)(v >> 32)) << 32);
 }
 
+// 1 if the word is not zero, else 0 -- as one v_min_u32 (the compiler turns min(x, 1) into compare + select through VCC,
+// two instructions and a wait state per pixel in the decoder's flag loop)
+__device__ __forceinline__ uint32_t nonzero_flag(uint32_t x)
+{
+    uint32_t r;
+    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t nonzero_flag(uint64_t x) { return nonzero_flag((uint32_t)x | (uint32_t)(x >> 32)); }
+
+// inclusive prefix sums of eight nibbles (each sum < 16), three shift-adds (left to itself the compiler multiplies by
+// 0x11111111: a quarter-rate instruction)
+__device__ __forceinline__ uint32_t nibble_prefix_sums(uint32_t p)
+{
+    asm("v_lshl_add_u32 %0, %0, 4, %0\n\tv_lshl_add_u32 %0, %0, 8, %0\n\tv_lshl_add_u32 %0, %0, 16, %0" : "+v"(p));
+    return p;
+}
+
+// bit s of the result = some bit of byte s of m is set (m is wave-uniform: scalar arithmetic)
+__device__ __forceinline__ uint32_t any_bit_per_byte(uint64_t m)
+{
+    m |= m >> 4; m |= m >> 2; m |= m >> 1;
+    m &= 0x0101010101010101ull;
+    return (uint32_t)((m * 0x0102040810204080ull) >> 56);        // bit 8 s -> bit 56 + s; no two products share a position
+}
+
 // kLabels: every 128-pixel segment is written in ONE of two forms, chosen here segment by segment:
 //   palette form  128 bytes in `labels` (the plane has one such block per segment): 64 bytes of 4-bit indices, one per
 //                 pixel, then the palette -- the words of the segment's PIECES (maximal runs of pixels with the same
@@ -518,23 +556,24 @@ __device__ __forceinline__ uint64_t wave_xor_scan(uint64_t v)
 //                 more than a handful of pieces, whether masks overlap or not;
 //   word form     the mask words in `maskbits`, as without labels, when the segment has more pieces than that.
 // The segment bitmap then has TWO uint32 per 4096 pixels: [2k] = segment holds a mask pixel, [2k + 1] = segment is in
-// word form.  The decoder is bound by its writes and the sweep by the number of 128-byte lines it fetches: a palette
-// segment is ONE line instead of four (32-bit words) or eight.
+// word form.  The sweep is bound by the number of 128-byte lines it fetches: a palette segment is ONE line instead of
+// four (32-bit words) or eight.
 template <typename WordT, bool kLabels>
 __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
     const int32_t *__restrict__ run_start, const int32_t *__restrict__ run_end,
     const int32_t *__restrict__ mask_run_offs, const int32_t *__restrict__ view_mask_offs,
     int64_t n_pixels, WordT *__restrict__ maskbits, uint32_t *__restrict__ segmap, int64_t seg_words,
-    uint8_t *__restrict__ labels, int64_t label_stride, int band_chunks)
+    uint8_t *__restrict__ labels, int64_t label_stride)
 {
-    __shared__ WordT lds[kBlock / kWave][kWaveChunk];
+    __shared__ __attribute__((aligned(32))) WordT lds[kBlock / kWave][kWaveChunk];
+    using V4 = WordT __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: band and chunk bounds stay in SGPRs
     WordT *bits = lds[wave];
     const int v = blockIdx.y;
     const int g0 = view_mask_offs[v];
     const int nm = view_mask_offs[v + 1] - g0;
-    const int64_t band64 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kWaveChunk * band_chunks;
+    const int64_t band64 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kWaveChunk * kWaveChunks;
     if (band64 >= n_pixels) return;                  // wave-uniform
     const int band0 = (int)band64, npx = (int)n_pixels;               // n_pixels < 2^31 (checked by the entry point)
     WordT *img = maskbits + (int64_t)v * n_pixels;
@@ -554,15 +593,20 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
         if (cur < hi) { rs = run_start[cur]; re = run_end[cur]; }
         if (cur + 1 < hi) { ns = run_start[cur + 1]; ne = run_end[cur + 1]; }
     }
-    constexpr int kHalf = 256, kQ = 4;                // lane owns words [4l, 4l+4) of each 256-word sub-block
+    // this lane's words [16 l, 16 l + 16) of the chunk: four 4-word slots (chunk_word_slot moves whole slots)
+    int own[kPx / 4];
 #pragma unroll
-    for (int h = 0; h < kSub; ++h)
+    for (int j = 0; j < kPx / 4; ++j) own[j] = chunk_word_slot(lane * kPx + 4 * j);
 #pragma unroll
-        for (int k = 0; k < kQ; ++k) bits[h * kHalf + lane * kQ + k] = 0;
+    for (int j = 0; j < kPx / 4; ++j) *reinterpret_cast<V4 *>(bits + own[j]) = V4{0, 0, 0, 0};
     lds_phase_fence();
     const WordT bit = (WordT)1 << (lane & (int)(sizeof(WordT) * 8 - 1));
     uint32_t *smap = segmap ? segmap + (int64_t)v * seg_words * (kLabels ? 2 : 1) : nullptr;
-    for (int c = 0; c < band_chunks; ++c) {
+    const int swz = own[0] ^ (lane * kPx);
+    const int sl = lane & 7, seg_of_lane = lane >> 3;                 // lane within its segment, segment within the chunk
+    const int m1 = sl >= 1 ? -1 : 0, m2 = sl >= 2 ? -1 : 0;           // lanes a segmented scan step may add into
+    constexpr int kPalMax = 64 / (int)sizeof(WordT);                   // 16 palette entries of 32 bits / 8 of 64 bits
+    for (int c = 0; c < kWaveChunks; ++c) {
         const int c0 = band0 + c * kWaveChunk;        // scalar
         if (c0 >= npx) break;
         const bool whole = npx - c0 >= kWaveChunk;    // every chunk but the image's last one
@@ -572,8 +616,8 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
         if (smap && !__ballot(rs < c1)) continue;
         if (lane < nm) {
             while (rs < c1) {
-                atomicXor(&bits[max(rs, c0) - c0], bit);
-                if (re < c1) atomicXor(&bits[re - c0], bit);
+                atomicXor(&bits[chunk_word_slot(max(rs, c0) - c0)], bit);
+                if (re < c1) atomicXor(&bits[chunk_word_slot(re - c0)], bit);
                 if (re > c1) break;                   // run continues into the next chunk
                 ++cur;
                 rs = ns; re = ne;
@@ -581,105 +625,115 @@ __global__ __launch_bounds__(kBlock) void rle_to_maskbits_kernel(
             }
         }
         lds_phase_fence();                            // toggles of all lanes are in LDS
-        WordT loc[kSub][kQ], tot[kSub];
+        WordT x[kPx];
 #pragma unroll
-        for (int h = 0; h < kSub; ++h) {
-            WordT acc = 0;
-#pragma unroll
-            for (int k = 0; k < kQ; ++k) {
-                acc ^= bits[h * kHalf + lane * kQ + k];
-                loc[h][k] = acc;
-                bits[h * kHalf + lane * kQ + k] = 0;  // ready for the next chunk
-            }
-            tot[h] = acc;
+        for (int j = 0; j < kPx / 4; ++j) {
+            const V4 t = *reinterpret_cast<const V4 *>(bits + own[j]);
+            x[4 * j] = t[0]; x[4 * j + 1] = t[1]; x[4 * j + 2] = t[2]; x[4 * j + 3] = t[3];
         }
-        lds_phase_fence();                            // re-zeroing is ordered before the next chunk's toggles
-        WordT carry_in = 0;                                          // XOR of the sub-blocks before this one
-        using Vec = __attribute__((ext_vector_type(4))) uint32_t;
-        WordT *img_c = img + c0;                                     // scalar base; the lane offset never changes
-        uint8_t *lab_c = kLabels ? labels + (int64_t)v * label_stride + c0 : nullptr;
-        uint32_t seg_bits = 0;                                       // scalar: non-zero 128-pixel segments of the chunk
-        uint32_t fmt_bits = 0;                                       // scalar (kLabels): segments written in word form
+        // a pixel whose toggle word is not zero starts a new piece (its word differs from its left neighbour's):
+        // one flag per pixel, spread to the low bit of a nibble
+        uint32_t f_lo = 0, f_hi = 0;
 #pragma unroll
-        for (int h = 0; h < kSub; ++h) {
-            const WordT incl = wave_xor_scan(tot[h]);
-            const WordT carry = incl ^ tot[h] ^ carry_in;            // exclusive prefix, continuing the chunk
-            carry_in ^= __shfl(incl, kWave - 1);
-            WordT outv[kQ];
-            WordT any = 0;
+        for (int k = 0; k < 8; ++k) {
+            f_lo |= nonzero_flag(x[k]) << (4 * k);
+            f_hi |= nonzero_flag(x[8 + k]) << (4 * k);
+        }
+        // XOR of the lane's 16 toggles as a tree of three-input XORs (v_bitop3), one wave scan of the totals, then ONE chain
+        // of 16 XORs from the coverage at the lane's first pixel
+        WordT tot = 0;
 #pragma unroll
-            for (int k = 0; k < kQ; ++k) { outv[k] = loc[h][k] ^ carry; any |= outv[k]; }
-            bool store = true;
-            if (smap) {
-                // 128-pixel segments = 32 consecutive lanes: all-zero segments are not stored at all, the
-                // sweep learns from the bitmap (one bit per segment) that there is nothing to gather there
-                const uint64_t nz = __ballot(any != 0);
-                const uint32_t lo = (uint32_t)nz, up = (uint32_t)(nz >> 32);
-                seg_bits |= ((lo ? 1u : 0u) | (up ? 2u : 0u)) << (2 * h);
-                store = (lane < 32 ? lo : up) != 0;
-            }
-            const int q = h * kHalf + lane * kQ;                     // word of the chunk
-            bool as_labels = false;
-            if (kLabels) {
-                // Palette of the segment (= this half-wave's 128 words, 4 consecutive ones per lane): the words are piecewise
-                // constant along the row -- they change where a run of some mask starts or ends -- so the palette simply
-                // lists the PIECES in order (repeats allowed, the empty word included) and a pixel keeps the number of its
-                // piece: a transition flag per pixel, one 32-lane prefix sum, no loop.  More pieces than entries: word form.
-                static_assert(kQ == 4, "a lane's four palette indices are one 16-bit store");
-                constexpr int kPalMax = 64 / (int)sizeof(WordT);             // 16 entries of 32 bits / 8 of 64 bits
-                const int li = lane & 31;
-                const WordT prev = (sizeof(WordT) == 8) ? (WordT)__shfl_up((unsigned long long)outv[3], 1)
-                                                        : (WordT)__shfl_up((unsigned)outv[3], 1);
-                const int t0 = (li != 0 && outv[0] != prev) ? 1 : 0;         // pixel 0 of the segment opens piece 0
-                const int t1 = outv[1] != outv[0] ? 1 : 0, t2 = outv[2] != outv[1] ? 1 : 0, t3 = outv[3] != outv[2] ? 1 : 0;
-                const int cnt = t0 + t1 + t2 + t3;
-                int incl = cnt;                                              // inclusive prefix over the half's 32 lanes
-#define BFF_DPP_ADD(ctrl, rows) incl += __builtin_amdgcn_update_dpp(0, incl, ctrl, rows, 0xF, false)
-                BFF_DPP_ADD(0x111, 0xF);    // row_shr:1
-                BFF_DPP_ADD(0x112, 0xF);    // row_shr:2
-                BFF_DPP_ADD(0x114, 0xF);    // row_shr:4
-                BFF_DPP_ADD(0x118, 0xF);    // row_shr:8
-                BFF_DPP_ADD(0x142, 0xA);    // row_bcast:15 -> rows 1 and 3 (the second row of either half)
-#undef BFF_DPP_ADD
-                const int id0 = incl - cnt + t0, id1 = id0 + t1, id2 = id1 + t2, id3 = id2 + t3;
-                const int pieces_lo = __builtin_amdgcn_readlane(incl, 31) + 1, pieces_hi = __builtin_amdgcn_readlane(incl, 63) + 1;
-                const bool overflow = (lane < 32 ? pieces_lo : pieces_hi) > kPalMax;
-                const unsigned nib = (unsigned)id0 | ((unsigned)id1 << 4) | ((unsigned)id2 << 8) | ((unsigned)id3 << 12);
-                const uint64_t ov = __ballot(overflow);
-                const uint32_t slo = (uint32_t)ov, sup = (uint32_t)(ov >> 32);
-                fmt_bits |= ((slo ? 1u : 0u) | (sup ? 2u : 0u)) << (2 * h);
-                as_labels = !overflow;
-                const int seg0 = h * kHalf + (lane >> 5) * 128;          // first pixel of this half's segment in the chunk
-                if (store && as_labels && c0 + seg0 < c1) {              // the plane is padded to whole segments
-                    uint8_t *seg = lab_c + seg0;
-                    *reinterpret_cast<uint16_t *>(seg + 2 * li) = (uint16_t)nib;
+        for (int k = 0; k < kPx; k += 4) tot ^= (x[k] ^ x[k + 1]) ^ (x[k + 2] ^ x[k + 3]);
+        WordT carry = wave_xor_scan(tot) ^ tot;       // coverage just before this lane's first pixel
+        asm volatile("" : "+v"(carry));
+        x[0] ^= carry;
+#pragma unroll
+        for (int k = 1; k < kPx; ++k) x[k] ^= x[k - 1];
+        // lanes whose 16 words are not all zero: a piece starts after the lane's first pixel (two different words), or
+        // all 16 equal the first one and that is not zero
+        const uint64_t nz = __ballot(((f_lo & ~1u) | f_hi) != 0 || x[0] != 0);
+        const uint32_t occ8 = smap ? any_bit_per_byte(nz) : 0xFFu;   // scalar: segments of the chunk that are stored
+        if (!occ8) continue;                          // (only reachable with a bitmap: nothing was toggled, LDS is still zero)
+        // the words go back to LDS: the palette below picks single words out of them, the word form re-reads them coalesced
+#pragma unroll
+        for (int j = 0; j < kPx / 4; ++j)
+            *reinterpret_cast<V4 *>(bits + own[j]) = V4{x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]};
+        uint32_t wf8 = occ8;                          // scalar: segments written as words
+        if (kLabels) {
+            // Palette of the segment (= 8 lanes x 16 pixels): the words are piecewise constant along the row, so the palette
+            // simply lists the PIECES in order (repeats allowed, the empty word included) and a pixel keeps the number of
+            // its piece = the number of piece starts up to it, the segment's first pixel opening piece 0 whatever its toggle.
+            if (sl == 0) f_lo &= ~1u;
+            const uint32_t p_lo = nibble_prefix_sums(f_lo), p_hi = nibble_prefix_sums(f_hi);     // <= 8 each: no carries
+            const int c_lo = (int)(p_lo >> 28), cnt = c_lo + (int)(p_hi >> 28);
+            int incl = cnt;                           // inclusive prefix over the 8 lanes of the segment
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false) & m1;     // row_shr:1
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false) & m2;     // row_shr:2
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xA, false);          // row_shr:4 into lanes 4-7, 12-15
+            const int base = incl - cnt;              // pieces started before this lane's pixels (piece 0 is open)
+            const int pieces = __shfl(incl, lane | 7) + 1;
+            const bool overflow = pieces > kPalMax;
+            const uint32_t ovf8 = any_bit_per_byte(__ballot(overflow));
+            wf8 = occ8 & ovf8;
+            if (((occ8 & ~ovf8) >> seg_of_lane) & 1) {
+                const int seg0 = seg_of_lane * 128;                    // first pixel of this lane's segment in the chunk
+                if (c0 + seg0 < c1) {                                  // the plane is padded to whole segments
+                    // piece numbers are < 16 here: adding the same base to every nibble cannot carry
+                    uint32_t b_lo = (uint32_t)base, b_hi = (uint32_t)(base + c_lo);
+                    b_lo |= b_lo << 4; b_lo |= b_lo << 8; b_lo |= b_lo << 16;
+                    b_hi |= b_hi << 4; b_hi |= b_hi << 8; b_hi |= b_hi << 16;
+                    uint8_t *seg = labels + (int64_t)v * label_stride + c0 + seg0;
+                    *reinterpret_cast<uint2 *>(seg + 8 * sl) = make_uint2(p_lo + b_lo, p_hi + b_hi);
                     WordT *pal = reinterpret_cast<WordT *>(seg + 64);
-                    if (t0 || li == 0) pal[id0] = outv[0];                // the pixels that open a piece write its word
-                    if (t1) pal[id1] = outv[1];
-                    if (t2) pal[id2] = outv[2];
-                    if (t3) pal[id3] = outv[3];
+                    if (sl == 0) pal[0] = x[0];
+                    // the pixels that start a piece write its word (a lane rarely has more than one or two)
+                    uint64_t rem = (uint64_t)f_lo | ((uint64_t)f_hi << 32);
+                    int id = base;
+                    lds_phase_fence();                                 // this lane's words are in LDS
+                    while (rem) {                                      // two per round: one LDS latency for both
+                        const int k0 = (__ffsll((unsigned long long)rem) - 1) >> 2;
+                        rem &= rem - 1;
+                        const bool two = rem != 0;
+                        const int k1 = two ? (__ffsll((unsigned long long)rem) - 1) >> 2 : k0;
+                        rem &= rem - 1;                                // 0 stays 0
+                        const WordT w0 = bits[(lane * kPx + k0) ^ swz];         // chunk_word_slot: the XOR pattern is the lane's
+                        const WordT w1 = bits[(lane * kPx + k1) ^ swz];
+                        pal[id + 1] = w0;
+                        if (two) pal[id + 2] = w1;
+                        id += 2;
+                    }
                 }
             }
-            if (store && !as_labels) {
-                if (whole || c0 + q + kQ <= c1) {     // `whole` is scalar: the common case has no per-lane bounds test
-                    const Vec *src = reinterpret_cast<const Vec *>(outv);
-                    Vec *dst = reinterpret_cast<Vec *>(img_c + q);             // chunk starts are multiples of 1024 words
+        }
+        if (wf8) {
+            // word form, read back coalesced: lane l takes words 4l..4l+3 of each 256-word block (= 2 segments)
+            lds_phase_fence();
+            WordT *img_c = img + c0;
 #pragma unroll
-                    for (int k = 0; k < (int)(kQ * sizeof(WordT) / 16); ++k) dst[k] = src[k];
+            for (int h = 0; h < kWaveChunk / 256; ++h) {
+                if (!((wf8 >> (2 * h + (lane >> 5))) & 1)) continue;
+                const int q = h * 256 + lane * 4;
+                const V4 t = *reinterpret_cast<const V4 *>(bits + chunk_word_slot(q));
+                if (whole || c0 + q + 4 <= c1) {
+                    *reinterpret_cast<V4 *>(img_c + q) = t;            // chunk starts are multiples of 1024 words
                 } else {
 #pragma unroll
-                    for (int k = 0; k < kQ; ++k)
-                        if (c0 + q + k < c1) img_c[q + k] = outv[k];
+                    for (int k = 0; k < 4; ++k)
+                        if (c0 + q + k < c1) img_c[q + k] = t[k];
                 }
             }
         }
+        lds_phase_fence();                            // every read of the words is done
+#pragma unroll
+        for (int j = 0; j < kPx / 4; ++j) *reinterpret_cast<V4 *>(bits + own[j]) = V4{0, 0, 0, 0};   // ready for the next chunk
+        lds_phase_fence();                            // ordered before the next chunk's toggles
         // a chunk's 8 segments are 8 consecutive bits of one bitmap word (chunks start at multiples of 1024 pixels)
-        if (smap && seg_bits && lane == 0) {
+        if (smap && lane == 0) {
             if (kLabels) {
-                atomicOr(smap + 2 * (c0 >> 12), seg_bits << ((c0 >> 7) & 31));
-                if (fmt_bits) atomicOr(smap + 2 * (c0 >> 12) + 1, fmt_bits << ((c0 >> 7) & 31));
+                atomicOr(smap + 2 * (c0 >> 12), occ8 << ((c0 >> 7) & 31));
+                if (wf8) atomicOr(smap + 2 * (c0 >> 12) + 1, wf8 << ((c0 >> 7) & 31));
             } else {
-                atomicOr(smap + (c0 >> 12), seg_bits << ((c0 >> 7) & 31));
+                atomicOr(smap + (c0 >> 12), occ8 << ((c0 >> 7) & 31));
             }
         }
     }
@@ -752,9 +806,7 @@ static int rle_decode(const int32_t *run_start, const int32_t *run_end, const in
     BFF_LIMIT(n_pixels < (1ll << 31), "bff_rle_to_maskbits: image larger than 2^31 pixels");
     if (n_views == 0) return BFF_OK;
     BFF_REQUIRE(mask_run_offs && view_mask_offs && maskbits, "bff_rle_to_maskbits: null pointer");   // run arrays may be empty (NULL)
-    static const int band_env = [] { const char *e = getenv("BFF_RLE_BAND"); return e ? atoi(e) : 0; }();
-    const int band = band_env > 0 ? band_env : kWaveChunks;
-    dim3 grid((unsigned)ceil_div(n_pixels, (int64_t)kWaveChunk * band * (kBlock / kWave)), (unsigned)n_views);
+    dim3 grid((unsigned)ceil_div(n_pixels, (int64_t)kWaveChunk * kWaveChunks * (kBlock / kWave)), (unsigned)n_views);
     const int64_t seg_words = ceil_div(ceil_div(n_pixels, 128), 32);
     BFF_REQUIRE(!labels || segmap, "bff_rle_to_labels: the label plane needs its segment bitmap");
     if (segmap) {
@@ -765,16 +817,16 @@ static int rle_decode(const int32_t *run_start, const int32_t *run_end, const in
     hipStream_t st = as_stream(stream);
     if (word_bits == 32 && !labels)
         rle_to_maskbits_kernel<uint32_t, false><<<grid, kBlock, 0, st>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words, nullptr, 0, band);
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words, nullptr, 0);
     else if (word_bits == 32)
         rle_to_maskbits_kernel<uint32_t, true><<<grid, kBlock, 0, st>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words, labels, ls, band);
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint32_t *)maskbits, segmap, seg_words, labels, ls);
     else if (!labels)
         rle_to_maskbits_kernel<uint64_t, false><<<grid, kBlock, 0, st>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words, nullptr, 0, band);
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words, nullptr, 0);
     else
         rle_to_maskbits_kernel<uint64_t, true><<<grid, kBlock, 0, st>>>(
-            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words, labels, ls, band);
+            run_start, run_end, mask_run_offs, view_mask_offs, n_pixels, (uint64_t *)maskbits, segmap, seg_words, labels, ls);
     return launched("bff_rle_to_maskbits");
 }
 
