@@ -334,6 +334,9 @@ def main():
                     help="skip the host-inclusive leg (every step takes host arrays -- reference formats, raw 16-bit depth -- "
                          "through the overlapped ingestion pipeline before the device path; reported as `host_inclusive`)")
     args = ap.parse_args()
+    # the host side of the GPU path makes only tiny torch CPU calls; left at the default every one of them opens an OpenMP
+    # region as wide as the host (256 logical cores on the GPU box).  cpu_baseline sets its own thread count afterwards.
+    torch.set_num_threads(int(os.environ.get("BFF_TORCH_THREADS", "4")))
     if args.shape == "c5":
         return bench_cosine(args)
     if args.cpu_stagewise:

@@ -61,6 +61,14 @@ def launch_ranks(argv=None):
     return subprocess.run(cmd).returncode
 
 
+def _host_threads():
+    """The host side makes only tiny torch CPU calls; by default each opens an OpenMP region as wide as the machine
+    (times the ranks of a node).  BFF_TORCH_THREADS overrides (0: leave torch's setting alone)."""
+    n = int(os.environ.get("BFF_TORCH_THREADS", "4"))
+    if n > 0:
+        torch.set_num_threads(n)
+
+
 def init_ranks():
     """-> (rank, world size, device).  Under torchrun: one GPU per rank over RCCL (backend "nccl");
     BFF_REHEARSE_ON_ONE_GPU=1 puts every rank on cuda:0 with gloo collectives -- only to rehearse the N > 1 code
@@ -96,6 +104,7 @@ def projection_main(argv=None):
         return rc
     cfg = load_config(args.config)
     _lib.load()
+    _host_threads()
     cls = args.cls
     from .distributed import shard_scenes
     from .pipeline import project_stream
@@ -177,6 +186,7 @@ def refinement_main(argv=None):
         return rc
     cfg = load_config(args.config)
     _lib.load()
+    _host_threads()
     cls = args.cls
     from .distributed import ClassBatch, shard_scenes
     rank, ws, device = init_ranks()

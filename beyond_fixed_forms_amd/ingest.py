@@ -47,7 +47,9 @@ def host_lib():
         lib.bff_host_decode_depth_pngs.argtypes = [py_object, c_void_p, c_int, c_int, c_void_p, c_int]
         lib.bff_host_decode_depth_pngs.restype = c_longlong
         lib.bff_host_abi.restype = c_int
-        if lib.bff_host_abi() != 2:
+        lib.bff_host_gather_bytes.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p]
+        lib.bff_host_gather_bytes.restype = c_longlong
+        if lib.bff_host_abi() != 3:
             raise _lib.BffLibraryError(f"{HOST_LIB_PATH}: unexpected ABI; rebuild")
         _host = lib
     return _host
@@ -214,10 +216,19 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
                 (raw_depth is None and f0.shape != (h, w)):
             return prepare_scene(scene, cfg, device=device, with_viewed=with_viewed)   # mixed sizes / dtypes: slow path
         each = f0.nbytes
-        stage = staging.get("depth", each * len(frames))
-        if host_lib().bff_host_pack_frames(frames, stage.data_ptr(), each, n_threads) != len(frames):
-            return prepare_scene(scene, cfg, device=device, with_viewed=with_viewed)
-        flat = stage[:each * len(frames)]
+        # the frames may already lie, in upload order, in page-locked memory: a decoder that wrote them there
+        # (io.load_scene(staging=...) -> this loader's "depth" buffer) or the caller's own pinned block
+        staged = getattr(scene, "depth_staged", None) if raw_depth is not None else None
+        flat = None
+        if staged is not None and list(staged[1]) == depth_ids:
+            held = staged[0].buf.get("depth") if isinstance(staged[0], Staging) else staged[0]
+            if torch.is_tensor(held) and held.is_pinned() and held.numel() * held.element_size() >= each * len(frames):
+                flat = held.view(-1).view(torch.uint8)[:each * len(frames)]
+        if flat is None:
+            stage = staging.get("depth", each * len(frames))
+            if host_lib().bff_host_pack_frames(frames, stage.data_ptr(), each, n_threads) != len(frames):
+                return prepare_scene(scene, cfg, device=device, with_viewed=with_viewed)
+            flat = stage[:each * len(frames)]
         if raw_depth is not None:
             from .io import bilinear_taps
             hs, ws_ = f0.shape
@@ -261,18 +272,36 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
 
     lap("cloud (copy to pinned, enqueue, layout)")
     # ---- small tables: one pinned block, one copy
+    conf, conf_d = None, None
     if conf_list:
         dts = {c.dtype for c in conf_list}
         if len(dts) != 1:
             raise TypeError(f"mixed confidence dtypes {dts}")
-        conf = torch.cat([c.reshape(-1) for c in conf_list]).cpu()
+        if all(c.device.type == "cpu" and c.is_contiguous() for c in conf_list):
+            # host tensors (the mask_2d file's): gathered into the pinned staging by ONE native call.  torch.cat / reshape /
+            # numpy() per frame are ATen calls, each of which hands the GIL over and back: with the loader threads and the
+            # compute thread contending that cost 30-60 us per call, 8-18 ms per scene (BFF_INGEST_TRACE)
+            nf_c = len(conf_list)
+            esz = conf_list[0].element_size()
+            meta = np.empty((2, nf_c), dtype=np.int64)
+            meta[0] = [c.data_ptr() for c in conf_list]
+            meta[1] = [c.numel() * esz for c in conf_list]
+            total = int(meta[1].sum())
+            cstage = staging.get("conf", total)
+            if host_lib().bff_host_gather_bytes(meta[0].ctypes.data, meta[1].ctypes.data, nf_c, cstage.data_ptr()) != total:
+                raise ValueError("confidence tensors could not be gathered")
+            conf_d = cstage[:total].view(conf_list[0].dtype).to(dev, non_blocking=True)
+        else:
+            conf = torch.cat([c.reshape(-1) for c in conf_list])
     else:
         conf = torch.zeros(0, dtype=torch.float16)
+    lap("small tables: confidences")
     ids = {s: k for k, s in enumerate(dict.fromkeys(labels))}       # distinct label strings in order of first appearance
     if len(ids) <= 1:
         label_id = np.zeros(len(labels), dtype=np.int32)
     else:
         label_id = np.fromiter(map(ids.__getitem__, labels), dtype=np.int32, count=len(labels))
+    lap("small tables: label ids")
     tables = [np.asarray(a, dtype=np.int32) for a in (d_idx, f_mask, f_rowbase, f_nmask, f_flags, view_mask_offs)] + [label_id]
     sizes = [t.size for t in tables]
     tstage = staging.get("tables", 4 * sum(sizes) + 8 * inv.size + 64).numpy()
@@ -280,20 +309,27 @@ def prepare_scene_fast(scene, cfg, device="cuda", with_viewed=True, staging: Sta
     np.concatenate(tables, out=ti)
     at = (4 * sum(sizes) + 7) // 8 * 8
     tstage[at:at + 8 * inv.size].view(np.float64)[:] = inv.reshape(-1)
+    lap("small tables: pack")
     tdev = staging.buf["tables"][:at + 8 * inv.size].to(dev, non_blocking=True)
+    lap("small tables: enqueue")
     tint = tdev[:4 * sum(sizes)].view(torch.int32)
     cuts = np.cumsum([0] + sizes)
     d_idx_d, f_mask_d, f_rowbase_d, f_nmask_d, f_flags_d, vmo_d, label_d = (tint[cuts[k]:cuts[k + 1]] for k in range(7))
     inv_d = tdev[at:at + 8 * inv.size].view(torch.float64).view(nf, 16)
-    if conf.numel():                                 # through the staging too: a pin_memory() per scene is a hipHostMalloc
+    if conf_d is not None:
+        pass
+    elif conf.is_cuda:                               # already on a GPU (a caller that kept the detector's outputs there): no
+        conf_d = conf.to(dev)                        # round trip through the host, which would wait for this stream's uploads
+    elif conf.numel():                               # through the staging too: a pin_memory() per scene is a hipHostMalloc
         cstage = staging.get("conf", conf.numel() * conf.element_size())
         cview = cstage[:conf.numel() * conf.element_size()].view(conf.dtype)
         cview.copy_(conf)
         conf_d = cview.to(dev, non_blocking=True)
     else:
         conf_d = conf.to(dev)
+    lap("small tables: confidences to pinned + enqueue")
     staging.fence()                                  # the pinned buffers may be rewritten once these copies are done
-    lap("small tables")
+    lap("small tables: fence")
     return DeviceScene(
         scene_id=scene.scene_id, n_points=n, nw=nw, height=h, width=w,
         cam_intr=np.asarray(scene.cam_intr, dtype=np.float64)[:3, :3].copy(), xyz=xyz, tile_bounds=bounds, depth=depth_dev,
@@ -411,6 +447,9 @@ def bench_host_inclusive(scenes, cfg, device, query, sim, steps=40, n_loaders=4,
             view[k] = sc.depths_raw[f]
         sc.depths_raw = {f: view[k] for k, f in enumerate(order)}
         sc.depth_staged = (block, order)
+        # host formats: the mask_2d file's confidences are host tensors
+        sc.mask_2d = [dict(fr, confidences=fr["confidences"].cpu()) if torch.is_tensor(fr["confidences"]) and fr["confidences"].is_cuda
+                      else fr for fr in sc.mask_2d]
         host.append(sc)
     ing = Ingestor(cfg, device, n_loaders=n_loaders, native_threads=native_threads)
     from .pipeline import scene_streams

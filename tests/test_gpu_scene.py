@@ -552,6 +552,36 @@ def test_overlapped_ingestion_equals_prepare_scene(api):
     a, b = prepare_scene(raw, cfg, device=DEV), ingest.prepare_scene_fast(raw, cfg, device=DEV)
     assert a.depth is None and b.depth is None and torch.equal(a.depth_raw, b.depth_raw)      # resident as stored
     assert a.depth_size == b.depth_size == (cfg.height_2d // 2, cfg.width_2d // 2)           # frames in 8 x 8 tiles
+    # the same frames already in page-locked memory in upload order (what a decoder with a pinned output leaves): read in
+    # place, no packing; a block in another order is not trusted and takes the packing path -- same scene either way
+    from beyond_fixed_forms_amd.scene import viewed_frame_ids
+    ids = list(dict.fromkeys([fr["frame_id"][:-4] for fr in raw.mask_2d] + viewed_frame_ids(raw.color_files, cfg.downsample_ratio)))
+    f0 = raw.depths_raw[ids[0]]
+    real_lib, packs = ingest.host_lib(), []
+
+    class Counting:                                  # the native library with a counter on the packing entry point
+        def __getattr__(self, name):
+            if name == "bff_host_pack_frames":
+                packs.append(1)
+            return getattr(real_lib, name)
+
+    for id_list, packed in ((ids, 0), (ids[::-1], 1)):
+        block = torch.empty((len(id_list),) + tuple(f0.shape), dtype=torch.int16).pin_memory()
+        view = block.numpy().view(np.uint16)
+        for k, f in enumerate(id_list):
+            view[k] = raw.depths_raw[f]
+        st = copy.copy(raw)
+        st.depths_raw = {f: view[k] for k, f in enumerate(id_list)}
+        st.depth_staged = (block, id_list)
+        del packs[:]
+        ingest._host = Counting()
+        try:
+            c = ingest.prepare_scene_fast(st, cfg, device=DEV)
+        finally:
+            ingest._host = real_lib
+        torch.cuda.synchronize()
+        assert len(packs) == packed
+        assert torch.equal(c.depth_raw, a.depth_raw) and torch.equal(c.depth_index, a.depth_index)
     monkey_env = dict(os.environ)
     os.environ["BFF_DEPTH_RESIZE_PASS"] = "1"                # the separate scale + resize pass: float32 (H, W) images
     try:
