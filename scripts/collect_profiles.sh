@@ -8,6 +8,7 @@
 #   sq     SQ counters (wait / active / LDS conflicts) of the three chip-filling kernels, two passes
 #   cal    FETCH_SIZE on access patterns with a known number of distinct lines (scripts/diag_membw.py)
 #   bench  the bench lines of the same build
+#   n2     two ranks on the box's one GPU over gloo (BFF_REHEARSE_ON_ONE_GPU=1): the N > 1 code path of bench.py
 # Counter passes collect only this library's kernels (--kernel-include-regex): the synthetic scene generator issues
 # ~10^5 torch kernels before the timed region.  Every pass is summarised as soon as it ends; raw traces stay in /tmp.
 set -o pipefail
@@ -61,5 +62,9 @@ bench)
     for k in 1 2 3; do timeout -k 10 600 python3 bench.py 2>/dev/null | tail -1 > "$OUT/bench_c2_default_run$k.json"; done     # the driver's command: host_inclusive + cpu_baseline
     timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_c2_driver_style.json"
     echo "done: bench ($SECONDS s)" ;;
+n2)
+    BFF_REHEARSE_ON_ONE_GPU=1 timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port 29533 bench.py --gpus 2 --steps 24 --warmup 6 --no-cpu-baseline 2> "$OUT/bench_n2_rehearse.err" | grep '^{"metric"' | tail -1 > "$OUT/bench_n2_rehearse.json"
+    echo "done: n2 ($SECONDS s)" ;;
 esac; done
 ls -la "$OUT"
