@@ -2210,6 +2210,9 @@ int bff::merge_components_streams(const uint64_t *rows, int32_t n_rows, int64_t 
             st = as_stream(heavy_stream);
         }
         static const int diag_mode = [] { const char *e = getenv("BFF_MERGE_DIAG"); return e ? atoi(e) : 1; }();
+        // BFF_MERGE_LDS_PAD=<bytes> of unused dynamic LDS: fewer blocks of the tile pass per CU (53 KB each: three fill a CU's
+        // LDS and keep every other kernel in flight off that CU)
+        static const int lds_pad = [] { const char *e = getenv("BFF_MERGE_LDS_PAD"); return e ? atoi(e) : 0; }();
         if (diag && diag_mode == 2)   // block timeline only (BFF_MERGE_DIAG=2): production occupancy
             hipExtLaunchKernelGGL(merge_components_kernel<2>, dim3((unsigned)cap2), dim3(256), 0, st, ev0, ev1, 0,
                 rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
@@ -2219,7 +2222,7 @@ int bff::merge_components_streams(const uint64_t *rows, int32_t n_rows, int64_t 
                 rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
                 label_sorted, iou_thres, parent, nt, diag, list2, pass2, counts + 1, chunk_pop, do_split ? part2 : nullptr, partial, arrive);
         else
-            hipExtLaunchKernelGGL(merge_components_kernel<0>, dim3((unsigned)cap2), dim3(256), 0, st, ev0, ev1, 0,
+            hipExtLaunchKernelGGL(merge_components_kernel<0>, dim3((unsigned)cap2), dim3(256), (unsigned)lds_pad, st, ev0, ev1, 0,
                 rows, n_order, nw, sparse ? tile_mask : nullptr, mw, hist_sorted, (int)n_pos, row_sorted, area_sorted,
                 label_sorted, iou_thres, parent, nt, (int32_t *)nullptr, list2, pass2, counts + 1, chunk_pop, do_split ? part2 : nullptr, partial, arrive);
         if (two) {
