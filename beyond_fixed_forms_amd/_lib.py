@@ -79,7 +79,7 @@ PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, [
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
          "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
          "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class BffLibraryError(RuntimeError):

@@ -125,7 +125,15 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
                                   sc->frame_mask, sc->frame_rowbase, sc->frame_nmask, sc->frame_flags, ws->rows, n_rows, nw,
                                   ws->chunk_mask, ws->masked, ratio ? ws->viewed : nullptr, sc->tile_bounds, hv));
     if (two) BFF_TRY(hand_over(ws->events[1], hv, stream));
-    // a14 / a15: point filter, threshold stays on the device (header words 2, 3 = n_unique, thr)
+    // a14 / a15: point filter, threshold stays on the device (header words 2, 3 = n_unique, thr).  Nothing before the
+    // overlap resolution reads `keep`: with an aux stream the chain forks here and joins there.
+    const bool fork = ws->aux_stream && ws->aux_stream != stream && pr->filter_mode != 0 && !pr->filter_sort;
+    void *const main_stream = stream;
+    if (fork) {
+        BFF_REQUIRE(ws->aux_events[0] && ws->aux_events[1], "bff_scene_project: an aux stream needs the workspace's two aux events");
+        BFF_TRY(hand_over(ws->aux_events[0], main_stream, ws->aux_stream));
+        stream = ws->aux_stream;
+    }
     if (pr->filter_mode != 0) {
         if (pr->filter_sort) {          // the general formulation: sort all n values (more distinct ones than the set holds)
             BFF_TRY(bff_point_values(ws->masked, ratio ? ws->viewed : nullptr, n, ws->vals, stream));
@@ -142,6 +150,11 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
                                reinterpret_cast<const float *>(hdr + BFF_HDR_THR), 1, nw, ws->keep, stream));
     } else {
         BFF_TRY(bff_ratio_keep(ws->masked, nullptr, n, 0.0f, nullptr, 0, nw, ws->keep, stream));
+    }
+    if (fork) {
+        hipError_t ee = hipEventRecord(reinterpret_cast<hipEvent_t>(ws->aux_events[1]), as_stream(stream));
+        if (ee != hipSuccess) return fail((int)ee, "bff_scene_project: aux stream: %s", hipGetErrorString(ee));
+        stream = main_stream;
     }
     // a9-a12: statistics through the chunk flags, tile order (label, signature), components
     uint16_t *cpop = bff_merge_uses_chunk_bound(nw) ? ws->chunk_pop : nullptr;
@@ -171,6 +184,10 @@ extern "C" int bff_scene_project(const bff_scene *sc, const bff_scene_params *pr
     // last reader of the raw rows is done: give the arena its zeros back -- unless the host has to take the general
     // path (more groups than the device forms), which reads the rows again and clears them itself
     BFF_TRY(bff_clear_flagged_chunks_unless(ws->rows, n_rows, nw, ws->chunk_mask, info + 1, stream));
+    if (fork) {         // join: `keep` and the header's threshold words are complete
+        hipError_t ee = hipStreamWaitEvent(st, reinterpret_cast<hipEvent_t>(ws->aux_events[1]), 0);
+        if (ee != hipSuccess) return fail((int)ee, "bff_scene_project: aux stream: %s", hipGetErrorString(ee));
+    }
     // a16 + P:592-596: overlap decisions (one prefix OR in priority order), &= keep, both popcounts
     BFF_TRY(bff_resolve_overlaps_dev(ws->agg, cap, nw, hdr + BFF_HDR_SIZES(cap), ws->keep, hdr + BFF_HDR_BEFORE(cap),
                                      hdr + BFF_HDR_AFTER(cap), info, stream));

@@ -57,7 +57,8 @@ class WorkspaceStruct(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in _WS_PTRS] + [("sort_temp_bytes", c_size_t), ("zero_bytes", c_size_t),
                                                       ("hdr", c_void_p), ("hdr_host", c_void_p),
                                                       ("group_cap", c_int32), ("pad_", c_int32),
-                                                      ("heavy_stream", c_void_p), ("events", c_void_p * 4)]
+                                                      ("heavy_stream", c_void_p), ("events", c_void_p * 4),
+                                                      ("aux_stream", c_void_p), ("aux_events", c_void_p * 2)]
 
 
 # Scenes in flight on the device, one HIP stream (and one SceneWorkspace) each.  A scene's device work is a chain of
@@ -73,6 +74,10 @@ PIPELINE_DEPTH = 4
 # one of those kernels leaves the chip half idle on its own (the sweep's waves sit on gathers 2/3 of their time) and the
 # others fill it: OFF by default (0: everything on the scene's own stream).
 HEAVY_STREAMS = int(os.environ.get("BFF_HEAVY_STREAMS", "0"))
+# BFF_AUX_STREAM=1: a second stream per workspace for the point filter's threshold chain (fork after the sweep, join
+# before the overlap resolution).  It shortens a scene's device span by 0.04 ms and costs a sixth of the throughput
+# (config 2: 961-984 vs 1149-1155 scenes/s: eight streams contend for the hardware queues): OFF by default.
+AUX_STREAM = os.environ.get("BFF_AUX_STREAM", "0") == "1"
 
 _TRACE_ISSUE = bool(os.environ.get("BFF_TRACE_ISSUE"))       # report scene calls that take more than 2 ms to enqueue
 _scene_streams = {}
@@ -203,6 +208,15 @@ class SceneWorkspace:
                 if not all(evs):
                     raise _lib.BffLibraryError("bff_event_create failed")
                 ws.struct.events = (c_void_p * 4)(*evs)
+            if AUX_STREAM:
+                # the point filter's threshold chain runs beside the components chain (bff_scene_workspace.aux_stream)
+                lib = _lib.load()
+                ws.aux = torch.cuda.Stream(device=st.device)
+                ws.struct.aux_stream = c_void_p(ws.aux.cuda_stream)
+                evs = [lib.bff_event_create() for _ in range(2)]
+                if not all(evs):
+                    raise _lib.BffLibraryError("bff_event_create failed")
+                ws.struct.aux_events = (c_void_p * 2)(*evs)
         return ws
 
     def _need(self, name, numel, dtype, zero=False):

@@ -32,7 +32,7 @@ extern "C" {
 #define BFF_E_ARG (-1)      /* null pointer / negative size / unsupported parameter */
 #define BFF_E_LIMIT (-2)    /* size beyond what a kernel supports (documented per call) */
 
-#define BFF_ABI_VERSION 6
+#define BFF_ABI_VERSION 7
 
 int bff_abi_version(void);
 const char *bff_last_error(void);
@@ -540,6 +540,10 @@ typedef struct bff_scene_workspace {
                                        chip-filling kernels run side by side as there are heavy streams while the scenes' chains of
                                        small kernels overlap freely.  NULL: everything on the call's stream */
     void *events[4];                /* four hipEvent_t of this workspace for the hand-overs between the two streams (heavy_stream != NULL) */
+    void *aux_stream;               /* optional second hipStream_t of this workspace: the point filter's threshold chain (four small
+                                       launches that only the overlap resolution at the end waits for) runs there, beside the row
+                                       statistics / tile order / components chain.  NULL: everything in one chain */
+    void *aux_events[2];            /* two hipEvent_t for the fork after the sweep and the join before the overlap resolution */
 } bff_scene_workspace;
 
 /* Header layout (int32 words). */
