@@ -310,8 +310,10 @@ def compulsory_traffic(ds, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=25,
+                    help="timed steps; a step is ONE QUERY CLASS per GPU: --class-batch (8) scenes through projection + the class's "
+                         "refinement (one similarity exchange + one gather at N > 1)")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape", default="c2", choices=list(SHAPES) + ["c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stagewise", action="store_true",
@@ -384,10 +386,11 @@ def main():
     if world > 1:
         dist.barrier()
 
-    timers = KernelTimers(reserve=4 * args.steps)      # events are created before the clock starts
+    cbatch = max(1, args.class_batch)
+    n_timed = args.steps * cbatch                      # scenes per rank inside the timed region: a step is one class batch
+    timers = KernelTimers(reserve=4 * n_timed)         # events are created before the clock starts
     depth = max(2, args.depth)
     streams = scene_streams(dev, depth)
-    cbatch = max(1, args.class_batch)
     host = {"front_issue_s": 0.0, "back_s": 0.0, "class_finish_s": 0.0}     # host wall time per part (back includes its sync wait)
     results, last_class = {}, {}
 
@@ -440,9 +443,9 @@ def main():
     # include one-time costs -- a workspace per stream (~6 ms each) and three more calls that block ~6 ms inside the
     # HIP runtime while its per-queue pools grow (traced with BFF_TRACE_ISSUE=1; none afterwards).  A driver run with
     # --warmup 5 --steps 20 would otherwise time those instead of the steady state.
-    priming = max(0, 16 - args.warmup)
+    priming = max(0, 16 - args.warmup * cbatch)
     run_steps(priming)
-    run_steps(args.warmup)
+    run_steps(args.warmup * cbatch)
 
     def fence():
         torch.cuda.synchronize()
@@ -461,7 +464,7 @@ def main():
         prof = cProfile.Profile()
         prof.enable()
     t0 = time.perf_counter()
-    run_steps(args.steps, timers)
+    run_steps(n_timed, timers)
     fence()
     elapsed = time.perf_counter() - t0
     if prof is not None:
@@ -469,10 +472,10 @@ def main():
         prof.disable()
         pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(35)
     n_exchanges = exchange.calls if exchange is not None else 0
-    host_ms = {"front_issue": round(host["front_issue_s"] / args.steps * 1e3, 4),
-               "back": round(host["back_s"] / args.steps * 1e3, 4),
-               "of_back_class_finish": round(host["class_finish_s"] / args.steps * 1e3, 4),
-               "of_which_waiting_for_gpu": round(_lib.sync_wait_s / args.steps * 1e3, 4)}
+    host_ms = {"front_issue": round(host["front_issue_s"] / n_timed * 1e3, 4),          # per SCENE
+               "back": round(host["back_s"] / n_timed * 1e3, 4),
+               "of_back_class_finish": round(host["class_finish_s"] / n_timed * 1e3, 4),
+               "of_which_waiting_for_gpu": round(_lib.sync_wait_s / n_timed * 1e3, 4)}
     host_ms["host_work"] = round(host_ms["front_issue"] + host_ms["back"] - host_ms["of_which_waiting_for_gpu"], 4)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -485,7 +488,7 @@ def main():
     if not args.no_pipeline:
         was = args.no_pipeline
         args.no_pipeline = True
-        run_steps(min(2 * n_scenes, args.steps), seq_timers)
+        run_steps(min(2 * n_scenes, n_timed), seq_timers)
         args.no_pipeline = was
         fence()
 
@@ -507,7 +510,7 @@ def main():
     upload_leg = None
     if world == 1 and not args.no_host_inclusive:
         from beyond_fixed_forms_amd.ingest import bench_host_inclusive
-        upload_leg = bench_host_inclusive(scenes, cfg, dev, QUERY, sim, steps=min(max(args.steps, 24), 48),
+        upload_leg = bench_host_inclusive(scenes, cfg, dev, QUERY, sim, steps=min(max(n_timed, 24), 48),
                                           n_loaders=int(os.environ.get("BFF_BENCH_LOADERS", "4")),
                                           native_threads=int(os.environ.get("BFF_BENCH_NATIVE_THREADS", "4")))
 
@@ -551,10 +554,11 @@ def main():
         l2_bytes = mt["chunk_visits"] * 128 * 64            # every visited chunk: 128 rows x 8 words staged through LDS
         out = {
             "metric": "scenes/sec (2D->3D projection+refinement), 200k pts x 300 views",
-            "value": world * args.steps / elapsed, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "value": world * n_timed / elapsed, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.shape}: 1 scene/GPU per step, {n} pts x {len(scenes[0].mask_2d)} mask views + "
+            "config": {"workload": f"{args.shape}: one query class of {cbatch} scenes per GPU and step (every scene through projection "
+                                   f"and refinement pass 1, then the class's threshold + pass 2), each scene {n} pts x {len(scenes[0].mask_2d)} mask views + "
                                    f"{ds.n_viewed} viewed frames @{h}x{w}, {m} masks/view (Ins={ds.n_rows}), "
                                    f"stage-1 S1={len(scenes[0].stage1['ins'])}, 198x768 f16 text bank; inputs RESIDENT in "
                                    f"HBM (uploaded before the timed region); depth " +
@@ -563,9 +567,11 @@ def main():
                                     f"{', 8x8-texel tiles' if ds.depth_size else ''}), bilinear resize "
                                     f"per point inside the sweep" if ds.depth_raw is not None else "float32 (H, W)") +
                                    f"; {n_scenes} different scenes rotate through the loop",
-                       "scenes_per_step": world, "priming_steps_in_setup": priming,
-                       "sharding": "one scene per GPU and step; scenes of one rank form query classes of class_batch scenes: ONE "
-                                   "all-gather of similarity sets + ONE RCCL gather of final masks per class (none at N = 1)",
+                       "scenes_per_step": world * cbatch, "scenes_in_timed_region": world * n_timed,
+                       "priming_scenes_in_setup": priming,
+                       "sharding": "one query class of class_batch scenes per GPU and step (the reference thresholds once per class, "
+                                   "R:316-324): ONE all-gather of similarity sets + ONE RCCL gather of final masks per step (none at "
+                                   "N = 1); `--class-batch 1` is round 2's one-scene step",
                        "class_batch": cbatch, "similarity_exchanges_in_timed_region": n_exchanges,
                        "pipelining": "none" if args.no_pipeline else
                        f"{depth} HIP streams: the device work of the next {depth - 1} scene(s) overlaps the host half of scene i",
@@ -590,7 +596,7 @@ def main():
                                "l2_bytes_staged": l2_bytes, "achieved": l2_bytes / (mc_alone * 1e-3) / 1e9,
                                "peak": 34500.0, "unit": "GB/s (L2, MI355X_MICROARCH.md)",
                                "frac": l2_bytes / (mc_alone * 1e-3) / 1e9 / 34500.0, **mt},
-            "host_ms": host_ms, "scene_call_device_span_ms": spans,      # wall time of the host thread per step: issuing, the host half, and the part of it spent blocked on the GPU
+            "host_ms": host_ms, "scene_call_device_span_ms": spans,      # wall time of the host thread per SCENE: issuing, the host half, and the part of it spent blocked on the GPU
             "kernels_ms": {k: round(vv[2], 4) for k, vv in ks.items()},   # the kernels' own durations (events on the dispatch)
             "result": {"per_scene (stage2_instances, final_masks)": [results.get(k) for k in range(n_scenes)],
                        "last_class_on_rank0": gathered_check},

@@ -56,15 +56,15 @@ cal)
     summarize gather_stride ;;
 bench)
     for s in c2 c1 c5; do timeout -k 10 300 $B --shape $s 2>/dev/null | tail -1 > "$OUT/bench_$s.json"; done
-    timeout -k 10 400 $B --shape c4 --scenes 2 --steps 40 --warmup 6 2>/dev/null | tail -1 > "$OUT/bench_c4.json"
+    timeout -k 10 400 $B --shape c4 --scenes 2 --steps 10 --warmup 2 2>/dev/null | tail -1 > "$OUT/bench_c4.json"
     timeout -k 10 300 $B --no-pipeline 2>/dev/null | tail -1 > "$OUT/bench_c2_no_pipeline.json"
-    timeout -k 10 400 $B --shape c4 --scenes 2 --steps 20 --warmup 4 --no-pipeline 2>/dev/null | tail -1 > "$OUT/bench_c4_no_pipeline.json"
+    timeout -k 10 400 $B --shape c4 --scenes 2 --steps 5 --warmup 1 --no-pipeline 2>/dev/null | tail -1 > "$OUT/bench_c4_no_pipeline.json"
     for k in 1 2 3; do timeout -k 10 600 python3 bench.py 2>/dev/null | tail -1 > "$OUT/bench_c2_default_run$k.json"; done     # the driver's command: host_inclusive + cpu_baseline
     timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_c2_driver_style.json"
     echo "done: bench ($SECONDS s)" ;;
 n2)
     BFF_REHEARSE_ON_ONE_GPU=1 timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
-        --master-port 29533 bench.py --gpus 2 --steps 24 --warmup 6 --no-cpu-baseline 2> "$OUT/bench_n2_rehearse.err" | grep '^{"metric"' | tail -1 > "$OUT/bench_n2_rehearse.json"
+        --master-port 29533 bench.py --gpus 2 --steps 12 --warmup 2 --no-cpu-baseline 2> "$OUT/bench_n2_rehearse.err" | grep '^{"metric"' | tail -1 > "$OUT/bench_n2_rehearse.json"
     echo "done: n2 ($SECONDS s)" ;;
 esac; done
 ls -la "$OUT"
