@@ -1413,13 +1413,26 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restr
     __syncthreads();
     const int need = min_members > 1 ? min_members : 1;
     const bool loops = 1.0f > thr;                                  // a non-empty row is adjacent to itself iff 1 > thr
-    for (int c0 = 0; c0 < n; c0 += 1024) {
+    constexpr int kAhead = 4;                                      // chunks whose loads are in flight together
+    for (int d0 = 0; d0 < n; d0 += 1024 * kAhead) {
+        int szv[kAhead], arv[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int c = d0 + u * 1024 + tid;
+            const bool root = c < n && comp[c] == c;
+            szv[u] = root ? count[c] : -1;                             // -1: not a root
+            arv[u] = root ? area[c] : 0;
+        }
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const int c0 = d0 + u * 1024;
+        if (c0 >= n) break;                                            // block-uniform
         const int c = c0 + tid;
         bool valid = false, is_void = false;
         int sz = 0;
-        if (c < n && comp[c] == c) {
-            sz = count[c];
-            is_void = sz == 1 && !(area[c] > 0 && loops);           // isolated row without a self loop: the reference's []
+        if (szv[u] >= 0) {
+            sz = szv[u];
+            is_void = sz == 1 && !(arv[u] > 0 && loops);            // isolated row without a self loop: the reference's []
             valid = !is_void && sz >= need;
         }
         const uint64_t bal = __ballot(valid);
@@ -1435,6 +1448,7 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restr
         __syncthreads();
         if (tid == 0) { int t = 0; for (int q = 0; q < 16; ++q) t += wsum[q]; s_base += t; }
         __syncthreads();
+      }
     }
     const int k_all = s_base, k = min(k_all, cap);
     {
@@ -1492,17 +1506,28 @@ __global__ __launch_bounds__(256) void group_members_kernel(const int32_t *__res
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int root = first[g];
     int base = offs[g], it = 0;
-    for (int i0 = 0; i0 < n; i0 += 256, it ^= 1) {
-        const int i = i0 + threadIdx.x;
-        const bool m = i < n && comp[i] == root;
-        const uint64_t bal = __ballot(m);
-        if (lane == 0) wcnt[it][wave] = __popcll(bal);
-        __syncthreads();                                   // double-buffered counters: one barrier per step
-        int before = 0, total = 0;
+    constexpr int kAhead = 4;                                  // steps whose loads are in flight together
+    for (int j0 = 0; j0 < n; j0 += 256 * kAhead) {
+        int cv[kAhead];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int c = wcnt[it][q]; total += c; if (q < wave) before += c; }
-        if (m) members[base + before + __popcll(bal & ((1ull << lane) - 1))] = i;
-        base += total;
+        for (int u = 0; u < kAhead; ++u) {
+            const int i = j0 + u * 256 + (int)threadIdx.x;
+            cv[u] = i < n ? comp[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u, it ^= 1) {
+            const int i = j0 + u * 256 + (int)threadIdx.x;
+            if (j0 + u * 256 >= n) break;                      // block-uniform
+            const bool m = cv[u] == root;                      // roots are >= 0
+            const uint64_t bal = __ballot(m);
+            if (lane == 0) wcnt[it][wave] = __popcll(bal);
+            __syncthreads();                                   // double-buffered counters: one barrier per step
+            int before = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int c = wcnt[it][q]; total += c; if (q < wave) before += c; }
+            if (m) members[base + before + __popcll(bal & ((1ull << lane) - 1))] = i;
+            base += total;
+        }
     }
 }
 
