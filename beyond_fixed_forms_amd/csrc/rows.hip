@@ -1414,6 +1414,8 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restr
     const int need = min_members > 1 ? min_members : 1;
     const bool loops = 1.0f > thr;                                  // a non-empty row is adjacent to itself iff 1 > thr
     constexpr int kAhead = 4;                                      // chunks whose loads are in flight together
+    __shared__ int wsum2[2][16];
+    int base = 0, it = 0;
     for (int d0 = 0; d0 < n; d0 += 1024 * kAhead) {
         int szv[kAhead], arv[kAhead];
 #pragma unroll
@@ -1436,20 +1438,22 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restr
             valid = !is_void && sz >= need;
         }
         const uint64_t bal = __ballot(valid);
-        if (lane == 0) wsum[wave] = __popcll(bal);
+        if (lane == 0) wsum2[it][wave] = __popcll(bal);
         if (is_void) atomicAdd(&s_void, 1);
-        __syncthreads();
-        int g = s_base + __popcll(bal & ((1ull << lane) - 1));
-        for (int q = 0; q < wave; ++q) g += wsum[q];
+        __syncthreads();                                   // double-buffered counters: one barrier per chunk
+        int g = base + __popcll(bal & ((1ull << lane) - 1)), total = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int cq = wsum2[it][q]; total += cq; if (q < wave) g += cq; }
         if (valid) {
             if (g < cap) { sizes[g] = sz; first[g] = c; s_sz[g] = sz; }
             atomicMax(&s_max, sz);
         }
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int q = 0; q < 16; ++q) t += wsum[q]; s_base += t; }
-        __syncthreads();
+        base += total;                                     // every thread keeps the running group count
+        it ^= 1;
       }
     }
+    if (tid == 0) s_base = base;
+    __syncthreads();
     const int k_all = s_base, k = min(k_all, cap);
     {
         // exclusive prefix sums of the groups' sizes and 32-member slice counts over the k <= 512 groups: thread g owns
@@ -1462,11 +1466,11 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t *__restr
             if (lane >= d) { io += uo; is += us; }
         }
         __syncthreads();                               // wsum was last read two barriers ago; reuse it for both sums
-        __shared__ int wsum2[16];
-        if (lane == 63) { wsum[wave] = io; wsum2[wave] = is; }
+        __shared__ int wsum3[16];
+        if (lane == 63) { wsum[wave] = io; wsum3[wave] = is; }
         __syncthreads();
         int bo = 0, bs = 0;
-        for (int q = 0; q < wave; ++q) { bo += wsum[q]; bs += wsum2[q]; }
+        for (int q = 0; q < wave; ++q) { bo += wsum[q]; bs += wsum3[q]; }
         if (tid < k) { s_off[tid] = bo + io - sz; s_soff[tid] = bs + is - sl; }
         if (tid == k - 1 || (k == 0 && tid == 0)) {
             const int o = k ? bo + io : 0, so = k ? bs + is : 0;
