@@ -299,7 +299,12 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
             // words, one 128-byte line) or the mask words (rle_to_maskbits_kernel<.., true>).  A point gathers its index
             // byte or its word -- both kinds in flight together --, then the palette entry out of the line the index
             // came from.
+            // The palette entry's address depends on the index byte: a second, dependent round trip.  The first 16 bytes of
+            // the palette (entries 0-3 of 32 bits, 0-1 of 64) are therefore fetched WITH the index byte -- same 128-byte
+            // line, no extra line -- and only a pixel of a later piece pays the dependent load.
+            constexpr int kSpec = 16 / (int)sizeof(WordT);
             uint32_t lb[kPPT];
+            uint4 first4[kPPT];
             bool pal_go[kPPT];
 #pragma unroll
             for (int j = 0; j < kPPT; ++j) {
@@ -309,14 +314,30 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
                 const bool words = (fbits[j] >> sb) & 1;
                 lb[j] = 0;
                 wv[j] = 0;
+                first4[j] = make_uint4(0, 0, 0, 0);
                 pal_go[j] = go && !words;
-                if (go && !words) lb[j] = limg[(pix[j] & ~127) + ((pix[j] & 127) >> 1)];
+                if (go && !words) {
+                    lb[j] = limg[(pix[j] & ~127) + ((pix[j] & 127) >> 1)];
+                    first4[j] = *reinterpret_cast<const uint4 *>(limg + (pix[j] & ~127) + 64);
+                }
                 if (go && words) wv[j] = mimg[pix[j]];
             }
 #pragma unroll
             for (int j = 0; j < kPPT; ++j) {
                 const uint32_t idx = (lb[j] >> (4 * (pix[j] & 1))) & 15u;
-                if (pal_go[j]) wv[j] = *reinterpret_cast<const WordT *>(limg + (pix[j] & ~127) + 64 + sizeof(WordT) * idx);
+                if (pal_go[j]) {
+                    if (idx < (uint32_t)kSpec) {
+                        if (sizeof(WordT) == 4) {
+                            wv[j] = (WordT)(idx == 0 ? first4[j].x : idx == 1 ? first4[j].y : idx == 2 ? first4[j].z : first4[j].w);
+                        } else {
+                            const uint64_t e0 = (uint64_t)first4[j].x | ((uint64_t)first4[j].y << 32);
+                            const uint64_t e1 = (uint64_t)first4[j].z | ((uint64_t)first4[j].w << 32);
+                            wv[j] = (WordT)(idx == 0 ? e0 : e1);
+                        }
+                    } else {
+                        wv[j] = *reinterpret_cast<const WordT *>(limg + (pix[j] & ~127) + 64 + sizeof(WordT) * idx);
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -333,7 +354,11 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
             mcount[j] += (sizeof(WordT) == 8) ? __popcll((uint64_t)wv[j]) : __popc((uint32_t)wv[j]);
             present |= wv[j];
         }
+#ifdef BFF_DIAG_NO_ROW_STORES
+        if (false) {
+#else
         if (has_masks) {                                   // wave-uniform
+#endif
             // the wave's 32-B sector (kPPT words) of each of the frame's nm rows: lane -> (row lane/4 + 16 i,
             // word lane%4).  Most waves see no mask at all in a given frame: the caller zeroed the rows.
             const int64_t rb = frame_rowbase[f];
