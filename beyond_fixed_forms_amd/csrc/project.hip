@@ -302,7 +302,8 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
             // The palette entry's address depends on the index byte: a second, dependent round trip.  The first 16 bytes of
             // the palette (entries 0-3 of 32 bits, 0-1 of 64) are therefore fetched WITH the index byte -- same 128-byte
             // line, no extra line -- and only a pixel of a later piece pays the dependent load.
-            constexpr int kSpec = 16 / (int)sizeof(WordT);
+            // (32-bit words only: with 64-bit words two entries cover too few pixels -- config 4 ran 1.55 -> 1.69 ms with them)
+            constexpr int kSpec = sizeof(WordT) == 4 ? 4 : 0;
             uint32_t lb[kPPT];
             uint4 first4[kPPT];
             bool pal_go[kPPT];
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
                 pal_go[j] = go && !words;
                 if (go && !words) {
                     lb[j] = limg[(pix[j] & ~127) + ((pix[j] & 127) >> 1)];
-                    first4[j] = *reinterpret_cast<const uint4 *>(limg + (pix[j] & ~127) + 64);
+                    if (kSpec) first4[j] = *reinterpret_cast<const uint4 *>(limg + (pix[j] & ~127) + 64);
                 }
                 if (go && words) wv[j] = mimg[pix[j]];
             }
@@ -327,13 +328,7 @@ __global__ __launch_bounds__(kBlock) void project_views_kernel(
                 const uint32_t idx = (lb[j] >> (4 * (pix[j] & 1))) & 15u;
                 if (pal_go[j]) {
                     if (idx < (uint32_t)kSpec) {
-                        if (sizeof(WordT) == 4) {
-                            wv[j] = (WordT)(idx == 0 ? first4[j].x : idx == 1 ? first4[j].y : idx == 2 ? first4[j].z : first4[j].w);
-                        } else {
-                            const uint64_t e0 = (uint64_t)first4[j].x | ((uint64_t)first4[j].y << 32);
-                            const uint64_t e1 = (uint64_t)first4[j].z | ((uint64_t)first4[j].w << 32);
-                            wv[j] = (WordT)(idx == 0 ? e0 : e1);
-                        }
+                        wv[j] = (WordT)(idx == 0 ? first4[j].x : idx == 1 ? first4[j].y : idx == 2 ? first4[j].z : first4[j].w);
                     } else {
                         wv[j] = *reinterpret_cast<const WordT *>(limg + (pix[j] & ~127) + 64 + sizeof(WordT) * idx);
                     }
