@@ -143,6 +143,23 @@ def _stream():
     return c_void_p(raw_stream())
 
 
+class _PinnedStream:
+    """(raw handle, torch stream) of the current stream, the handle taken the cheap way at once, the torch.cuda.Stream
+    object (8 us of Python to build) only when somebody asks for it -- most blocks only launch."""
+    __slots__ = ("raw", "_obj")
+
+    def __init__(self):
+        self.raw = c_void_p(raw_stream())
+        self._obj = None
+
+    def __getitem__(self, k):
+        if k == 0:
+            return self.raw
+        if self._obj is None:
+            self._obj = torch.cuda.current_stream()
+        return self._obj
+
+
 class launch_stream:
     """Look torch's current stream up once for a whole sequence of kernel launches (the lookup costs more
     than a launch).  Entry points such as run_projection / refine_class wrap their bodies in it; the stream
@@ -150,8 +167,7 @@ class launch_stream:
 
     def __enter__(self):
         self._outer = _cached_stream()
-        st = torch.cuda.current_stream()
-        _tls.cache = (c_void_p(st.cuda_stream), st)
+        _tls.cache = _PinnedStream()
         return self
 
     def __exit__(self, *exc):
