@@ -352,6 +352,13 @@ def main():
     rehearse = os.environ.get("BFF_REHEARSE_ON_ONE_GPU") == "1"
     if rehearse:
         local_rank = 0
+    # BFF_FORCE_COLLECTIVES=1 at N = 1: a process group of ONE rank over RCCL, and every class makes its exchange and its
+    # gather although nobody else is there -- what a single-GPU box can measure of the RCCL branch (config.collectives)
+    forced = world == 1 and os.environ.get("BFF_FORCE_COLLECTIVES") == "1"
+    if forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local_rank}"))
     if world > 1:
         if rehearse:
             dist.init_process_group("gloo")
@@ -382,8 +389,8 @@ def main():
     enc = bank_encoder(bank, index)
     sim = TextSimilarity(enc, dev)
     t_setup = time.perf_counter() - t0
-    exchange = bdist.ClassExchange("cpu" if rehearse else dev) if world > 1 else None     # sims + result-size bounds, one all-gather per class
-    if world > 1:
+    exchange = bdist.ClassExchange("cpu" if rehearse else dev) if (world > 1 or forced) else None     # sims + result-size bounds, one all-gather per class
+    if world > 1 or forced:
         dist.barrier()
 
     cbatch = max(1, args.class_batch)
@@ -573,6 +580,8 @@ def main():
                                    "R:316-324): ONE all-gather of similarity sets + ONE RCCL gather of final masks per step (none at "
                                    "N = 1); `--class-batch 1` is round 2's one-scene step",
                        "class_batch": cbatch, "similarity_exchanges_in_timed_region": n_exchanges,
+                       "collectives": ("RCCL, forced on a process group of one rank (BFF_FORCE_COLLECTIVES=1)" if forced else
+                                       "none (N = 1)" if world == 1 else "gloo rehearsal on one GPU" if rehearse else "RCCL"),
                        "pipelining": "none" if args.no_pipeline else
                        f"{depth} HIP streams: the device work of the next {depth - 1} scene(s) overlaps the host half of scene i",
                        "scene_variants": [SCENE_VARIANTS[k % len(SCENE_VARIANTS)]["kind"] for k in range(n_scenes)]},
@@ -607,7 +616,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scenes[0], cfg, bank_encoder(bank.float(), index))
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

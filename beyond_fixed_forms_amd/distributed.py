@@ -16,7 +16,16 @@ from typing import List, Sequence
 import torch
 import torch.distributed as dist
 
+import os
+
 MAX_SIMS = 256          # a class meets at most one similarity per ScanNet200 label (198) per query
+
+
+def _collectives(ws):
+    """Does a class exchange / gather anything?  With several ranks: yes.  BFF_FORCE_COLLECTIVES=1 also with ONE rank in an
+    initialised process group -- the way a single-GPU box executes the RCCL branch (stream of its own, pinned staging,
+    all_gather_into_tensor, gather) that otherwise first runs on the 8-GPU node (tests/test_gpu_scene.py)."""
+    return ws > 1 or (os.environ.get("BFF_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized())
 
 
 def _coll_device(t: torch.Tensor):
@@ -47,7 +56,7 @@ def exchange_similarities(local_sims: List[List[float]], device="cpu") -> List[L
     """All ranks' per-scene similarity lists -> one pooled list of lists (only the *set* of values
     matters to the threshold, refinement.py:321-324).  One flat all-gather of MAX_SIMS+1 doubles."""
     rank, ws = world()
-    if ws == 1:
+    if not _collectives(ws):
         return local_sims
     uniq = sorted(set(s for sims in local_sims for s in sims))
     if len(uniq) > MAX_SIMS:
@@ -92,7 +101,7 @@ class ClassExchange:
     def __call__(self, local_sims, bounds=(0, 1)):
         rank, ws = world()
         self.calls += 1
-        if ws == 1:
+        if not _collectives(ws):
             self.bounds = (int(bounds[0]), int(bounds[1]))
             return local_sims
         uniq = sorted(set(s for sims in local_sims for s in sims))
@@ -130,7 +139,7 @@ def gather_final_rows(rows: torch.Tensor, dst: int = 0, bounds=None):
     synchronisation -- every rank sends a [1 + max rows][max words] buffer whose first row holds its real
     (R, nw); dst gets the padded buffers back as `PaddedRows` (decoded on demand)."""
     rank, ws = world()
-    if ws == 1:
+    if not _collectives(ws):
         return [rows]
     dev = rows.device
     if bounds is not None:
@@ -269,7 +278,8 @@ class ClassBatch:
         self.device, self.text_prompt = device, text_prompt
         self.ids, self.s_max = list(all_ids), int(s_max)
         self.index = {sid: i for i, sid in enumerate(self.ids)}
-        self.exchange = exchange if exchange is not None else (ClassExchange(device) if ws > 1 else None)
+        self.multi = _collectives(ws)
+        self.exchange = exchange if exchange is not None else (ClassExchange(device) if self.multi else None)
         self.refiner = ClassRefiner(cfg, text_prompt, sim, device, exchange_sims=self.exchange)
         self.final = None
         self.gathered = None
@@ -278,9 +288,9 @@ class ClassBatch:
         return self.refiner.add(scene_id, stage1, stage2)
 
     def finish(self):
-        final = self.refiner.finish() if (self.refiner.order or self.ws > 1) else {}
+        final = self.refiner.finish() if (self.refiner.order or self.multi) else {}
         self.final = final
-        if self.ws > 1:
+        if self.multi:
             r_max, w_max = self.exchange.bounds
             width = max(w_max, 8)
             mat = pack_class_results(final, self.index, self.s_max, self.device, bounds=(r_max, width))
@@ -290,7 +300,7 @@ class ClassBatch:
 
     def results(self):
         """rank 0: {scene_id: FinalResult} for ALL scenes of the class; other ranks: their own shard."""
-        if self.ws == 1 or self.rank != 0:
+        if not self.multi or self.rank != 0:
             return self.final
         out = {}
         for g in self.gathered:                                 # the gathered headers are read here, not in the loop

@@ -388,6 +388,78 @@ def test_run_class_two_ranks_equals_single_process(api, over):
         assert np.array_equal(dense, e["ins"].numpy()) and torch.equal(conf, e["conf"]) and cls == e["final_class"]
 
 
+def _rccl_one_rank_worker(port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", BFF_FORCE_COLLECTIVES="1")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    from beyond_fixed_forms_amd import distributed as bd
+    from beyond_fixed_forms_amd.config import Config
+    from beyond_fixed_forms_amd.refinement import TextSimilarity
+    from beyond_fixed_forms_amd.synthetic import make_scene, make_text_bank
+    scenes = [make_scene("tiny", seed=50 + i) for i in range(3)]
+    for i, sc in enumerate(scenes):
+        sc.scene_id = f"scene{50 + i:04d}_00"
+    cfg = Config.with_defaults(width_2d=scenes[0].width, height_2d=scenes[0].height)
+    bank, index = make_text_bank(64, seed=7)
+    sim = TextSimilarity(bank_encoder(bank.float(), index), "cuda:0")
+    ex = bd.ClassExchange("cuda:0")
+    ids = [s.scene_id for s in scenes]
+    from beyond_fixed_forms_amd.pipeline import project_stream
+    batch = bd.ClassBatch(cfg, "table", sim, "cuda:0", ids, len(ids), exchange=ex)
+    project_stream(scenes, cfg, "cuda:0", lambda k, st1, res: batch.add(ids[k], st1, res), n_loaders=1)
+    out = batch.finish().results()                 # decoded from the buffers the RCCL gather delivered
+    assert dist.get_backend() == "nccl" and ex.calls == 1 and ex._comm is not None and batch.gathered is not None
+    # the plain helpers over RCCL as well
+    pooled = bd.exchange_similarities([[0.25, 0.5], [0.5]], device="cuda:0")
+    rows = bd.gather_final_rows(torch.arange(12, dtype=torch.int64, device="cuda:0").view(3, 4))
+    q.put(({sid: (None if f.rows is None else f.rows.cpu(), f.conf if isinstance(f.conf, list) else f.conf.cpu(), list(f.final_class),
+                  f.n_points) for sid, f in out.items()}, pooled, rows[0].cpu()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_branch_with_one_rank(api):
+    """The `nccl` (= RCCL) branch of the class's two collectives -- ClassExchange on a stream of its own with pinned
+    staging + all_gather_into_tensor, the gather of the packed result matrices, the plain helpers -- executed on this
+    box's one GPU as a process group of ONE rank (BFF_FORCE_COLLECTIVES=1: a class then exchanges and gathers although
+    nobody else is there).  Results decoded from the gathered buffers == the oracle's."""
+    import socket
+    import torch.multiprocessing as mp
+    from beyond_fixed_forms_amd.synthetic import make_scene, make_text_bank
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(port, q))
+    p.start()
+    got, pooled, rows = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert pooled == [[0.25, 0.5]] and torch.equal(rows, torch.arange(12, dtype=torch.int64).view(3, 4))
+    scenes = [make_scene("tiny", seed=50 + i) for i in range(3)]
+    for i, sc in enumerate(scenes):
+        sc.scene_id = f"scene{50 + i:04d}_00"
+    cfg = cfg_for(scenes[0])
+    bank, index = make_text_bank(64, seed=7)
+    enc = bank_encoder(bank.float(), index)
+    trip = []
+    for sc in scenes:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            trip.append((sc.scene_id, sc.stage1, pref.project_scene_ref(sc, cfg)))
+    exp = rref.refine_class_ref(trip, cfg, "table", enc)
+    assert sorted(got) == sorted(exp)
+    for sid, (rows, conf, cls, n_points) in got.items():
+        e = exp[sid]
+        if isinstance(e["ins"], list):
+            assert rows is None and cls == []
+            continue
+        n = e["ins"].shape[1]
+        dense = np.unpackbits(rows.numpy().view(np.uint8), axis=-1, bitorder="little")[:, :n].astype(bool)
+        assert n_points == n and np.array_equal(dense, e["ins"].numpy()) and torch.equal(conf, e["conf"]) and cls == e["final_class"]
+
+
 @pytest.mark.parametrize("enc_dtype", [torch.float32, torch.float16])
 def test_similarity_set_near_ties(api, enc_dtype):
     """The class threshold is sorted(set(similarities))[int(n * 0.2)] (R:321-324): it depends on which values TIE.
