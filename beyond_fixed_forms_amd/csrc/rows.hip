@@ -2018,9 +2018,13 @@ extern "C" int bff_cross_popcount_dev(const uint64_t *a, int32_t na, const uint6
     BFF_REQUIRE(a && b && inter && k_dev, "bff_cross_popcount_dev: null pointer");
     const int64_t tiles = ceil_div(nb, kT) * ceil_div(na, kT);
     int64_t k_split = nw;
-    if (tiles < 512) {
-        k_split = ceil_div(ceil_div(nw * tiles, 512), kKW) * kKW;
-        if (k_split < 2 * kKW) k_split = 2 * kKW;
+    // few tiles (the refinement's S1 x (K + S1) product: a dozen, most of their rows zero): split the words until ~2048
+    // blocks run, down to one LDS stage each -- the partial counts meet through atomics on non-zero entries only
+    // (config 2, K = 20 / 100: 40 / 44 us with 512 blocks of >= 2 stages, 26 / 35 us with 2048 of >= 1)
+    constexpr int64_t target = 2048;
+    if (tiles < target) {
+        k_split = ceil_div(ceil_div(nw * tiles, target), kKW) * kKW;
+        if (k_split < kKW) k_split = kKW;
     }
     const int64_t nz = ceil_div(nw, k_split);
     hipError_t e = zero_async(inter, sizeof(int32_t) * (size_t)na * nb, as_stream(stream));
