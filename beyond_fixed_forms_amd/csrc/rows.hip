@@ -2289,10 +2289,12 @@ extern "C" int bff_permute_bits(const uint64_t *rows_in, int32_t n_rows, int64_t
 }
 
 // Rows at least this long are OR-ed through their chunk flags (BFF_OR_SPARSE_MIN_NW): config 4 reads 4.8 GB of rows
-// that are ~1 % occupied; at config 2 the dense pass (234 MB) and the flagged one measured the same end to end.
+// that are ~1 % occupied.  Config 2 (3125 words): round 2 measured the dense pass (234 MB) and the flagged one the same end
+// to end; with four scenes in flight on the shorter chain the flagged pass is 21 vs 40-45 us and worth ~5 % of the
+// throughput (the dense read competed with the other scenes' kernels for HBM), so the limit is 1024 words now.
 static int64_t or_sparse_min_words()
 {
-    static const int64_t v = [] { const char *e = getenv("BFF_OR_SPARSE_MIN_NW"); return e ? atoll(e) : 8192ll; }();
+    static const int64_t v = [] { const char *e = getenv("BFF_OR_SPARSE_MIN_NW"); return e ? atoll(e) : 1024ll; }();
     return v;
 }
 
