@@ -2118,7 +2118,10 @@ extern "C" int32_t bff_merge_uses_chunk_bound(int64_t nw)
 {
     static const int forced = [] { const char *e = getenv("BFF_CHUNK_BOUND"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return forced != 0;
-    return ceil_div(nw > 0 ? nw : 1, kBins) >= 16 * kCW;
+    // from 4 chunks per histogram bin (2048 words = 131 k points).  Round 2 had it from 16 (config 4 only): at config 2 its
+    // table cost what it saved then; with the shorter chain and four scenes in flight it is 0.23 vs 0.295 ms for the tile
+    // pass alone and 1351-1363 vs 1205-1286 scenes/s
+    return ceil_div(nw > 0 ? nw : 1, kBins) >= 4 * kCW;
 }
 
 // entries of the second tile-pair list: every surviving pair once + the extra parts of the pairs that are split
