@@ -405,7 +405,7 @@ def main():
     def front(i, tm=None):
         t = time.perf_counter()
         k = i % n_scenes
-        with torch.cuda.stream(streams[i % depth]):
+        with _lib.on_stream(streams[i % depth]):
             fr = projection_front(dss[k], cfg, timers=tm, stage1=stage1s[k])
         host["front_issue_s"] += time.perf_counter() - t
         if trace_front is not None:
@@ -423,7 +423,7 @@ def main():
             t = time.perf_counter()
             ks = i % n_scenes
             j = i % cbatch
-            with torch.cuda.stream(streams[i % depth]):
+            with _lib.on_stream(streams[i % depth]):
                 res = projection_back(fr, want_groups=False)
                 if j == 0:
                     nb = min(cbatch, k - i)             # scenes of this class on every rank

@@ -78,8 +78,9 @@ PLAIN = {"bff_abi_version": (c_int32, []), "bff_last_error": (ctypes.c_char_p, [
          "bff_point_threshold_scratch_words": (c_int64, [c_int64]), "bff_point_threshold_capacity": (c_int32, []), "bff_point_threshold_capacity_set": (c_int32, [c_int32]), "bff_scene_header_words": (c_int32, [c_int32, c_int32]), "bff_scene_struct_bytes": (c_int32, [c_int32]),
          "bff_host_component_csr": (c_int32, [_P, _P, _I, _I, _P, _P, _P, _P]),
          "bff_profile_next_sweep": (c_int32, [_P, _P]), "bff_event_create": (c_void_p, []),
-         "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P])}
-ABI_VERSION = 7
+         "bff_event_destroy": (c_int32, [_P]), "bff_event_elapsed_ms": (c_int32, [_P, _P, _P]),
+         "bff_event_record": (c_int32, [_P, _P]), "bff_event_synchronize": (c_int32, [_P])}
+ABI_VERSION = 8
 
 
 class BffLibraryError(RuntimeError):
@@ -141,6 +142,38 @@ def _stream():
     if c is not None:
         return c[0]
     return c_void_p(raw_stream())
+
+
+_get_cur = getattr(torch._C, "_cuda_getCurrentStream", None)
+_set_cur = getattr(torch._C, "_cuda_setStream", None)
+
+
+class on_stream:
+    """`with torch.cuda.stream(st)` without its Python: the current stream's ids are read and set through the two C calls
+    torch.cuda.current_stream / set_stream wrap (a torch.cuda.stream block costs ~20 us of Python, and a scene enters two)."""
+    __slots__ = ("st", "prev", "ctx")
+
+    def __init__(self, st):
+        self.st, self.prev, self.ctx = st, None, None
+
+    def __enter__(self):
+        if _get_cur is None or _set_cur is None or self.st is None:
+            self.ctx = torch.cuda.stream(self.st)
+            return self.ctx.__enter__()
+        st = self.st
+        if _raw_device is not None and _raw_device() != st.device_index:      # another device: the full context
+            self.ctx = torch.cuda.stream(st)
+            return self.ctx.__enter__()
+        self.prev = _get_cur(st.device_index)                 # (stream_id, device_index, device_type)
+        _set_cur(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+        return st
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        p = self.prev
+        _set_cur(stream_id=p[0], device_index=p[1], device_type=p[2])
+        return False
 
 
 class _PinnedStream:
@@ -665,14 +698,18 @@ def upload(data, dtype, device):
         ring = _up_ring[(dtype, cap)] = [bufs, [b.numpy() for b in bufs], [None] * 8, 0]
     k = ring[3]
     ring[3] = (k + 1) & 7
+    lib = load()
     ev = ring[2][k]
     if ev is not None:
-        ev.synchronize()                       # the copy that last used this buffer (8 uploads ago) is long done
+        lib.bff_event_synchronize(ev)          # the copy that last used this buffer (8 uploads ago) is long done
     else:
-        ev = ring[2][k] = torch.cuda.Event()
+        ev = ring[2][k] = c_void_p(lib.bff_event_create())     # a hipEvent_t: recorded on the raw stream handle below
+        if not ev:
+            raise BffLibraryError("bff_event_create failed")
     np.copyto(ring[1][k][:n], a.reshape(-1), casting="same_kind")
     out = ring[0][k][:n].to(device, non_blocking=True)
-    ev.record()                                # on the current stream
+    if lib.bff_event_record(ev, _stream()) != 0:               # on the current stream (no torch stream lookup)
+        raise RuntimeError(f"bff_event_record failed: {lib.bff_last_error().decode()}")
     return out.reshape(shape)
 
 

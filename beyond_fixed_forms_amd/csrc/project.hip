@@ -785,6 +785,18 @@ extern "C" int bff_event_destroy(void *event)
     return e == hipSuccess ? BFF_OK : fail((int)e, "bff_event_destroy: %s", hipGetErrorString(e));
 }
 
+extern "C" int bff_event_record(void *event, void *stream)
+{
+    hipError_t e = hipEventRecord(reinterpret_cast<hipEvent_t>(event), as_stream(stream));
+    return e == hipSuccess ? BFF_OK : fail((int)e, "bff_event_record: %s", hipGetErrorString(e));
+}
+
+extern "C" int bff_event_synchronize(void *event)
+{
+    hipError_t e = hipEventSynchronize(reinterpret_cast<hipEvent_t>(event));
+    return e == hipSuccess ? BFF_OK : fail((int)e, "bff_event_synchronize: %s", hipGetErrorString(e));
+}
+
 extern "C" int bff_event_elapsed_ms(void *start_event, void *stop_event, float *ms)
 {
     BFF_REQUIRE(start_event && stop_event && ms, "bff_event_elapsed_ms: null pointer");

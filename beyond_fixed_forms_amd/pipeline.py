@@ -428,12 +428,12 @@ def project_stream(scenes, cfg, device, consume, n_loaders=2, with_stage1=True, 
             futs[i + lookahead] = ing.submit(scenes[i + lookahead])
         st = streams[i % depth]
         st.wait_event(ev)                       # the uploads ran on the loader's stream
-        with torch.cuda.stream(st):
+        with _lib.on_stream(st):
             return projection_front(ds, cfg, stage1=st1), st1
 
     def back(i, h):
         fr, st1 = h
-        with torch.cuda.stream(streams[i % depth]):
+        with _lib.on_stream(streams[i % depth]):
             consume(i, st1, projection_back(fr, want_groups=want_groups))
 
     try:

@@ -32,7 +32,7 @@ extern "C" {
 #define BFF_E_ARG (-1)      /* null pointer / negative size / unsupported parameter */
 #define BFF_E_LIMIT (-2)    /* size beyond what a kernel supports (documented per call) */
 
-#define BFF_ABI_VERSION 7
+#define BFF_ABI_VERSION 8
 
 int bff_abi_version(void);
 const char *bff_last_error(void);
@@ -176,6 +176,10 @@ int bff_profile_next_sweep(void *start_event, void *stop_event);
 void *bff_event_create(void);
 int bff_event_destroy(void *event);
 int bff_event_elapsed_ms(void *start_event, void *stop_event, float *ms);
+/* hipEventRecord / hipEventSynchronize on such an event (hosts that hold a raw stream handle: a torch.cuda.Event.record()
+ * looks the current stream up first, which costs more than the record). */
+int bff_event_record(void *event, void *stream);
+int bff_event_synchronize(void *event);
 
 /* ------------------------------------------------------------------------------------------
  * Bit-row primitives (a8-a13, a16-a20).
